@@ -1,0 +1,117 @@
+"""The CPU oracle replayed against the committed golden vectors (outputs of the REAL
+reference, see oracle/make_golden.py).  Runs everywhere, including the GPU box where
+/root/reference does not exist.  fp64 throughout; tolerance 1e-12 (the oracle is bit-exact
+against the reference with the NumPy/SciPy versions recorded in each fixture's `meta`).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.vi_oracle import (OracleVarInf, ONode, snapshot, restore, make_latent_dict)
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-12
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name), allow_pickle=False))
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def assert_snap(got, want, tol=TOL, phi_tol=None):
+    assert list(got['ids']) == list(want['ids'])
+    np.testing.assert_array_equal(got['parent'], want['parent'])
+    np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
+    np.testing.assert_allclose(got['alpha'], want['alpha'], rtol=tol, atol=tol)
+    np.testing.assert_allclose(got['sigma'], want['sigma'], rtol=tol, atol=tol)
+    np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=tol, atol=tol, equal_nan=True)
+    np.testing.assert_allclose(got['phi'], want['phi'], rtol=0, atol=tol if phi_tol is None else phi_tol)
+    assert float(got['decay']) == float(want['decay'])
+
+
+def meta(d):
+    import json
+    return json.loads(str(d['meta']))
+
+
+def rows_for(fpv, V, N):
+    lc = make_latent_dict(np.zeros((N, 1), np.float32), list(fpv))
+    vids = list(lc.keys())
+    pairs = [(v, f) for v in vids for f in lc[v].keys()]
+    assert len(vids) == V
+    return vids, pairs
+
+
+@pytest.mark.parametrize("name", ["traj_ref_shape.npz", "traj_dynamic.npz", "traj_single_video.npz"])
+def test_trajectory(name):
+    g = load(name)
+    m = meta(g)
+    vi = OracleVarInf(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    for ep in range(m['epochs']):
+        lc = make_latent_dict(g['Z%d' % ep], list(g['fpv']))
+        np.random.seed(13 + ep)
+        vi.update_variational_parameters(lc)
+        assert_snap(snapshot(vi), sub(g, 'e%d_' % ep))
+
+
+@pytest.mark.parametrize("name", ["phases_irregular.npz", "phases_ref_shape.npz"])
+def test_phases(name):
+    g = load(name)
+    m = meta(g)
+    fpv = list(g['fpv'])
+    N, V = int(sum(fpv)), len(fpv)
+    vids, pairs = rows_for(fpv, V, N)
+    vi = OracleVarInf(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    fac = lambda nid, par: ONode(nid, V, N, par, m['D'], 10.0, rng=np.random.RandomState(0))
+    restore(vi, sub(g, 'in_'), fac, vids, pairs)
+    assert_snap(snapshot(vi), sub(g, 'in_'))
+    Z = g['Z']
+    vi.compute_sigma_alpha(Z)
+    assert_snap(snapshot(vi), sub(g, 'm_'))
+    vi.compute_gamma()
+    assert_snap(snapshot(vi), sub(g, 'g_'))
+    on, before = vi.prior_tables()
+    leaves = vi.leaves()
+    np.testing.assert_allclose(np.asarray([on[l] for l in leaves]), g['on'], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(np.asarray([before[l] for l in leaves]), g['before'], rtol=TOL, atol=TOL)
+    np.testing.assert_allclose(vi.logits(Z), g['logits'], rtol=TOL, atol=TOL)
+    vi.compute_phi(Z)
+    assert_snap(snapshot(vi), sub(g, 'e_'))
+    np.testing.assert_allclose(vi.last_log_phi, g['log_phi'], rtol=0, atol=1e-10)
+    np.testing.assert_allclose([np.mean(l.phi) for l in leaves], g['leaf_mean_phi'], rtol=TOL)
+    np.testing.assert_allclose([vi.leaf_stdev(l.phi, Z, l.alpha) for l in leaves], g['leaf_stdev'], rtol=TOL)
+    thr = float(g['split_thr'])
+    np.random.seed(m.get('seed', 0))      # children alphas are overwritten by the k-means centres
+    ret = vi.split_nodes(vi.root, Z, thr)
+    assert bool(ret) == bool(g['split_ret'])
+    assert_snap(snapshot(vi), sub(g, 's_'))
+    vi.compute_phi(Z)
+    vi.merge_nodes(vi.root, Z, thr)
+    assert_snap(snapshot(vi), sub(g, 'x_'))
+
+
+def test_faithful_loop_form_is_identical():
+    """The per-frame loop + list.index form (what the CPU baseline times) == vectorised form."""
+    g = load("phases_irregular.npz")
+    m = meta(g)
+    fpv = list(g['fpv'])
+    N, V = int(sum(fpv)), len(fpv)
+    vids, pairs = rows_for(fpv, V, N)
+    outs = []
+    for faithful in (False, True):
+        vi = OracleVarInf(latent_code_size=m['D'], faithful_loops=faithful)
+        fac = lambda nid, par: ONode(nid, V, N, par, m['D'], 10.0, rng=np.random.RandomState(0))
+        restore(vi, sub(g, 'g_'), fac, vids, pairs)
+        outs.append(vi.logits(g['Z']))
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_weighted_kmeans_golden():
+    g = load("kmeans.npz")
+    for i in range(3):
+        c = OracleVarInf.weighted_kmeans(g['data%d' % i], g['w%d' % i], int(g['K%d' % i]))
+        np.testing.assert_allclose(c, g['centers%d' % i], rtol=0, atol=0)
