@@ -1,0 +1,321 @@
+// C-ABI entry points of libbnpvi (declared in include/bnpvi.h): argument validation, the
+// per-device context, and the host-side flattening of the Node hierarchy into SoA arrays.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace bnpvi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int Scratch::ensure(size_t need) {
+  if (need <= bytes) return BNPVI_OK;
+  if (ptr) {
+    BNPVI_HIP(hipFree(ptr));
+    ptr = nullptr;
+    bytes = 0;
+  }
+  size_t want = need + need / 4;
+  hipError_t e = hipMalloc(&ptr, want);
+  if (e != hipSuccess) {
+    ptr = nullptr;
+    set_error("hipMalloc(%zu) for workspace failed: %s", want, hipGetErrorString(e));
+    return BNPVI_ENOMEM;
+  }
+  bytes = want;
+  return BNPVI_OK;
+}
+
+void Scratch::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+template <typename T>
+static int upload(const std::vector<T>& h, T** d) {
+  size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
+  BNPVI_HIP(hipMalloc((void**)d, bytes));
+  if (!h.empty()) BNPVI_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return BNPVI_OK;
+}
+
+}  // namespace bnpvi
+
+using namespace bnpvi;
+
+extern "C" {
+
+int bnpvi_abi_version(void) { return BNPVI_ABI_VERSION; }
+
+const char* bnpvi_last_error(void) { return g_err; }
+
+int bnpvi_padded_dim(int D) {
+  // the E-step k-loop is unrolled over whole registers: templates exist for these widths
+  const int sizes[] = {8, 16, 32, 64, 128, 256};
+  for (int s : sizes)
+    if (D <= s) return s;
+  return -1;
+}
+
+int bnpvi_padded_leaves(int L) { return L <= 0 ? -1 : round_up(L, kTile); }
+
+int bnpvi_ctx_create(int device, bnpvi_ctx** out) {
+  BNPVI_REQUIRE(out != nullptr, "bnpvi_ctx_create: out is NULL");
+  int n = 0;
+  BNPVI_HIP(hipGetDeviceCount(&n));
+  BNPVI_REQUIRE(device >= 0 && device < n, "bnpvi_ctx_create: device %d out of range (%d visible)",
+                device, n);
+  BNPVI_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  BNPVI_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("libbnpvi is built for gfx950 (MI355X) only; device %d is %s", device,
+              prop.gcnArchName);
+    return BNPVI_EUNSUPPORTED;
+  }
+  bnpvi_ctx* c = new bnpvi_ctx();
+  c->device = device;
+  c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kNumCU;
+  *out = c;
+  return BNPVI_OK;
+}
+
+int bnpvi_ctx_destroy(bnpvi_ctx* ctx) {
+  if (!ctx) return BNPVI_OK;
+  (void)hipSetDevice(ctx->device);
+  ctx->slabs.release();
+  ctx->pack.release();
+  ctx->part.release();
+  ctx->red.release();
+  ctx->cols.release();
+  delete ctx;
+  return BNPVI_OK;
+}
+
+int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_t* is_leaf,
+                      bnpvi_tree** out) {
+  BNPVI_REQUIRE(ctx && parent && is_leaf && out, "bnpvi_tree_create: NULL argument");
+  BNPVI_REQUIRE(K >= 1, "bnpvi_tree_create: K=%d", K);
+  BNPVI_REQUIRE(parent[0] == -1, "bnpvi_tree_create: node 0 must be the root (parent -1)");
+  bnpvi_tree* t = new bnpvi_tree();
+  t->ctx = ctx;
+  t->K = K;
+  t->parent.assign(parent, parent + K);
+  t->depth.assign(K, 0);
+  std::vector<int> nchild(K, 0);
+  for (int k = 1; k < K; ++k) {
+    int p = parent[k];
+    if (p < 0 || p >= k || is_leaf[p]) {
+      set_error("bnpvi_tree_create: node %d has invalid parent %d (pre-order, non-leaf parents)", k, p);
+      delete t;
+      return BNPVI_EINVAL;
+    }
+    // pre-order: the parent must be node k-1 or one of its ancestors
+    int a = k - 1;
+    while (a != p && a > 0) a = parent[a];
+    if (a != p) {
+      set_error("bnpvi_tree_create: nodes are not in pre-order at node %d", k);
+      delete t;
+      return BNPVI_EINVAL;
+    }
+    t->depth[k] = t->depth[p] + 1;
+    nchild[p]++;
+  }
+  for (int k = 0; k < K; ++k) {
+    if (!is_leaf[k] && nchild[k] == 0) {
+      set_error("bnpvi_tree_create: internal node %d has no children", k);
+      delete t;
+      return BNPVI_EINVAL;
+    }
+  }
+  // children CSR (children in order of appearance == Node.children order)
+  t->child_ptr.assign(K + 1, 0);
+  for (int k = 0; k < K; ++k) t->child_ptr[k + 1] = t->child_ptr[k] + nchild[k];
+  t->child_idx.assign(K > 1 ? K - 1 : 0, 0);
+  {
+    std::vector<int> fill(t->child_ptr.begin(), t->child_ptr.end() - 1);
+    for (int k = 1; k < K; ++k) t->child_idx[fill[parent[k]]++] = k;
+  }
+  // DFS leaf numbering and [lo,hi) leaf range per node
+  t->leaf_of_node.assign(K, -1);
+  t->leaf_lo.assign(K, 0);
+  t->leaf_hi.assign(K, 0);
+  int L = 0;
+  for (int k = 0; k < K; ++k) {
+    t->leaf_lo[k] = L;
+    if (is_leaf[k]) {
+      t->leaf_of_node[k] = L;
+      t->node_of_leaf.push_back(k);
+      ++L;
+    }
+  }
+  for (int k = K - 1; k >= 0; --k) {
+    if (is_leaf[k]) {
+      t->leaf_hi[k] = t->leaf_lo[k] + 1;
+    } else {
+      int last = t->child_idx[t->child_ptr[k + 1] - 1];
+      t->leaf_hi[k] = t->leaf_hi[last];
+    }
+  }
+  t->L = L;
+  t->Lp = round_up(L, kTile);
+  // level lists
+  int maxd = 0;
+  for (int k = 0; k < K; ++k) maxd = t->depth[k] > maxd ? t->depth[k] : maxd;
+  t->nlevels = maxd + 1;
+  t->level_ptr.assign(t->nlevels + 1, 0);
+  for (int k = 0; k < K; ++k) t->level_ptr[t->depth[k] + 1]++;
+  for (int d = 0; d < t->nlevels; ++d) t->level_ptr[d + 1] += t->level_ptr[d];
+  t->level_nodes.assign(K, 0);
+  {
+    std::vector<int> fill(t->level_ptr.begin(), t->level_ptr.end() - 1);
+    for (int k = 0; k < K; ++k) t->level_nodes[fill[t->depth[k]]++] = k;
+  }
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  int rc = BNPVI_OK;
+  if ((rc = upload(t->parent, &t->d_parent)) || (rc = upload(t->depth, &t->d_depth)) ||
+      (rc = upload(t->leaf_of_node, &t->d_leaf_of_node)) ||
+      (rc = upload(t->node_of_leaf, &t->d_node_of_leaf)) ||
+      (rc = upload(t->leaf_lo, &t->d_leaf_lo)) || (rc = upload(t->leaf_hi, &t->d_leaf_hi)) ||
+      (rc = upload(t->child_ptr, &t->d_child_ptr)) || (rc = upload(t->child_idx, &t->d_child_idx)) ||
+      (rc = upload(t->level_nodes, &t->d_level_nodes))) {
+    bnpvi_tree_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return BNPVI_OK;
+}
+
+int bnpvi_tree_destroy(bnpvi_tree* t) {
+  if (!t) return BNPVI_OK;
+  void* ptrs[] = {t->d_parent,  t->d_depth,     t->d_leaf_of_node, t->d_node_of_leaf, t->d_leaf_lo,
+                  t->d_leaf_hi, t->d_child_ptr, t->d_child_idx,    t->d_level_nodes};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete t;
+  return BNPVI_OK;
+}
+
+int bnpvi_tree_num_leaves(const bnpvi_tree* t) { return t ? t->L : -1; }
+
+int bnpvi_tree_leaf_nodes(const bnpvi_tree* t, int32_t* out_host) {
+  BNPVI_REQUIRE(t && out_host, "bnpvi_tree_leaf_nodes: NULL argument");
+  memcpy(out_host, t->node_of_leaf.data(), sizeof(int32_t) * t->L);
+  return BNPVI_OK;
+}
+
+static int check_common(const char* fn, bnpvi_ctx* ctx, int64_t N, int D, int ldz) {
+  BNPVI_REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
+  BNPVI_REQUIRE(N >= 0 && N < (int64_t(1) << 40), "%s: N=%lld", fn, (long long)N);
+  int Dp = bnpvi_padded_dim(D);
+  BNPVI_REQUIRE(D >= 1 && Dp > 0, "%s: D=%d unsupported (1..256)", fn, D);
+  BNPVI_REQUIRE(ldz >= Dp && ldz % 4 == 0,
+                "%s: ldz=%d must be >= bnpvi_padded_dim(D)=%d and a multiple of 4", fn, ldz, Dp);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return BNPVI_OK;
+}
+
+int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
+                     const int32_t* vid, int64_t N, int D, int L, int V, int want_q,
+                     double* stats, double* mass, void* stream) {
+  int rc = check_common("bnpvi_leaf_stats", ctx, N, D, ldz);
+  if (rc) return rc;
+  BNPVI_REQUIRE(Z && phi && stats, "bnpvi_leaf_stats: NULL device pointer");
+  BNPVI_REQUIRE(L >= 1 && ldphi == bnpvi_padded_leaves(L),
+                "bnpvi_leaf_stats: ldphi=%d must equal bnpvi_padded_leaves(L=%d)", ldphi, L);
+  BNPVI_REQUIRE(mass == nullptr || (vid != nullptr && V >= 1),
+                "bnpvi_leaf_stats: mass requested without vid / V");
+  return launch_leaf_stats(ctx, Z, ldz, phi, ldphi, vid, N, D, L, V, want_q, stats, mass,
+                           (hipStream_t)stream);
+}
+
+int bnpvi_node_params(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* stats, int W, int D,
+                      double sB, double sZ, const double* alpha0, double* alpha, double* sigma,
+                      void* stream) {
+  BNPVI_REQUIRE(ctx && tree && stats && alpha && sigma, "bnpvi_node_params: NULL argument");
+  BNPVI_REQUIRE(D >= 1 && W >= 1 + D, "bnpvi_node_params: stats_width=%d < 1+D=%d", W, 1 + D);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_node_params(ctx, tree, stats, W, D, sB, sZ, alpha0, alpha, sigma,
+                            (hipStream_t)stream);
+}
+
+int bnpvi_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass, int V,
+                       double gamma_hyper, double* gamma, void* stream) {
+  BNPVI_REQUIRE(ctx && tree && mass && gamma, "bnpvi_gamma_update: NULL argument");
+  BNPVI_REQUIRE(V >= 1, "bnpvi_gamma_update: V=%d", V);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_gamma_update(ctx, tree, mass, V, gamma_hyper, gamma, (hipStream_t)stream);
+}
+
+int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamma,
+                      const double* sigma, int V, double sZ, float* prior, double* on,
+                      double* before, void* stream) {
+  BNPVI_REQUIRE(ctx && tree && gamma && sigma && prior, "bnpvi_prior_table: NULL argument");
+  BNPVI_REQUIRE(V >= 1, "bnpvi_prior_table: V=%d", V);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_prior_table(ctx, tree, gamma, sigma, V, sZ, prior, on, before,
+                            (hipStream_t)stream);
+}
+
+int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,
+                const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
+                double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
+                void* stream) {
+  int rc = check_common("bnpvi_estep", ctx, N, D, ldz);
+  if (rc) return rc;
+  BNPVI_REQUIRE(tree && Z && alpha && phi, "bnpvi_estep: NULL argument");
+  BNPVI_REQUIRE(mode == BNPVI_ESTEP_SOFT || mode == BNPVI_ESTEP_HARD, "bnpvi_estep: mode=%d", mode);
+  BNPVI_REQUIRE(mode == BNPVI_ESTEP_HARD || (prior && vid),
+                "bnpvi_estep: soft mode needs prior and vid");
+  return launch_estep(ctx, tree, Z, ldz, vid, N, D, alpha, prior, sZ, mode, phi, logphi, assign,
+                      estats, (hipStream_t)stream);
+}
+
+int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* w,
+                      int ldw, const float* center, int first, float* dist2, int64_t* best_row,
+                      float* best_score, void* stream) {
+  int rc = check_common("bnpvi_kmeans_pass", ctx, N, D, ldz);
+  if (rc) return rc;
+  BNPVI_REQUIRE(Z && w && dist2 && best_row && best_score, "bnpvi_kmeans_pass: NULL argument");
+  BNPVI_REQUIRE(N >= 1 && ldw >= 1, "bnpvi_kmeans_pass: N=%lld ldw=%d", (long long)N, ldw);
+  return launch_kmeans_pass(ctx, Z, ldz, N, D, w, ldw, center, first, dist2, best_row,
+                            best_score, (hipStream_t)stream);
+}
+
+int bnpvi_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out, int ld_out,
+                        int64_t N, int Lnew, const int32_t* src_host, const float* scale_host,
+                        void* stream) {
+  BNPVI_REQUIRE(ctx && in && out && src_host && scale_host, "bnpvi_remap_columns: NULL argument");
+  BNPVI_REQUIRE(Lnew >= 1 && ld_out == bnpvi_padded_leaves(Lnew) && ld_in >= 1 && in != out,
+                "bnpvi_remap_columns: Lnew=%d ld_out=%d ld_in=%d (out of place only)", Lnew, ld_out,
+                ld_in);
+  for (int j = 0; j < Lnew; ++j)
+    BNPVI_REQUIRE(src_host[j] >= 0 && src_host[j] < ld_in, "bnpvi_remap_columns: src[%d]=%d", j,
+                  src_host[j]);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_remap_columns(ctx, in, ld_in, out, ld_out, N, Lnew, src_host, scale_host,
+                              (hipStream_t)stream);
+}
+
+int bnpvi_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out, int K_new, int V,
+                      const int32_t* src_host, double gamma_hyper, void* stream) {
+  BNPVI_REQUIRE(ctx && in && out && src_host, "bnpvi_gamma_remap: NULL argument");
+  BNPVI_REQUIRE(K_old >= 1 && K_new >= 1 && V >= 1 && in != out,
+                "bnpvi_gamma_remap: K_old=%d K_new=%d V=%d (out of place only)", K_old, K_new, V);
+  for (int k = 0; k < K_new; ++k)
+    BNPVI_REQUIRE(src_host[k] < K_old, "bnpvi_gamma_remap: src[%d]=%d", k, src_host[k]);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_gamma_remap(ctx, in, K_old, out, K_new, V, src_host, gamma_hyper,
+                            (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Shared host-side declarations for libbnpvi (gfx950 only; no CUDA/portability layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/bnpvi.h"
+
+namespace bnpvi {
+
+void set_error(const char* fmt, ...);
+
+#define BNPVI_HIP(call)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      ::bnpvi::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                         __FILE__, __LINE__);                                        \
+      return BNPVI_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+#define BNPVI_REQUIRE(cond, ...)                 \
+  do {                                           \
+    if (!(cond)) {                               \
+      ::bnpvi::set_error(__VA_ARGS__);           \
+      return BNPVI_EINVAL;                       \
+    }                                            \
+  } while (0)
+
+#define BNPVI_LAUNCH_CHECK()                                                           \
+  do {                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                 \
+    if (e_ != hipSuccess) {                                                            \
+      ::bnpvi::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_),    \
+                         __FILE__, __LINE__);                                          \
+      return BNPVI_EHIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+constexpr int kTile = 32;          // MFMA 32x32 tile edge
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grow-only device scratch buffer.
+struct Scratch {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need);
+  void release();
+};
+
+}  // namespace bnpvi
+
+struct bnpvi_ctx {
+  int device = 0;
+  int num_cu = bnpvi::kNumCU;
+  bnpvi::Scratch slabs;      // partial-sum slabs (fp64)
+  bnpvi::Scratch pack;       // packed leaf parameters for the E-step (fp32)
+  bnpvi::Scratch part;       // per-frame softmax partials of the streamed E-step
+  bnpvi::Scratch red;        // arg-max partials of the k-means pass
+  bnpvi::Scratch cols;       // column maps of remap_columns
+};
+
+struct bnpvi_tree {
+  bnpvi_ctx* ctx = nullptr;
+  int K = 0, L = 0, Lp = 0, nlevels = 0;
+  // host copies (pre-order node numbering, DFS leaf numbering)
+  std::vector<int32_t> parent, depth, leaf_of_node, node_of_leaf, leaf_lo, leaf_hi;
+  std::vector<int32_t> child_ptr, child_idx, level_ptr, level_nodes;
+  // device copies
+  int32_t *d_parent = nullptr, *d_depth = nullptr, *d_leaf_of_node = nullptr,
+          *d_node_of_leaf = nullptr, *d_leaf_lo = nullptr, *d_leaf_hi = nullptr,
+          *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_level_nodes = nullptr;
+};
+
+// kernels' launchers (one per .hip file)
+namespace bnpvi {
+
+int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
+                      const int32_t* vid, int64_t N, int D, int L, int V, int want_q,
+                      double* stats, double* mass, hipStream_t s);
+
+int launch_node_params(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D,
+                       double sB, double sZ, const double* alpha0, double* alpha, double* sigma,
+                       hipStream_t s);
+
+int launch_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, int V,
+                        double gamma_hyper, double* gamma, hipStream_t s);
+
+int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
+                       const double* sigma, int V, double sZ, float* prior, double* on,
+                       double* before, hipStream_t s);
+
+int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
+                 const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
+                 double sZ, int mode, float* phi, float* logphi, int32_t* assign,
+                 double* estats, hipStream_t s);
+
+int launch_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D,
+                       const float* w, int ldw, const float* center, int first, float* dist2,
+                       int64_t* best_row, float* best_score, hipStream_t s);
+
+int launch_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out, int ld_out,
+                         int64_t N, int Lnew, const int32_t* src_host, const float* scale_host,
+                         hipStream_t s);
+
+int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out, int K_new, int V,
+                       const int32_t* src_host, double gamma_hyper, hipStream_t s);
+
+}  // namespace bnpvi

@@ -1,0 +1,241 @@
+// E-step host dispatch and the DP-independent kernels (operand packing, the normalisation
+// pass of the streamed regime, slab reduction).  The MFMA kernels live in estep_kernels.h and
+// are instantiated per padded latent dim in estep_inst.hip.
+#include "estep_kernels.h"
+
+namespace bnpvi {
+
+// ------------------------------------------------------------------------------------------
+// pack leaf parameters: alpha (fp64, [K][D], pre-order) -> fp32 operand order; cvec = -|a|^2/2
+// ------------------------------------------------------------------------------------------
+__global__ void pack_leaves_kernel(const double* __restrict__ alpha, int D, int DP,
+                                   const int32_t* __restrict__ node_of_leaf, int L, int Lp,
+                                   float* __restrict__ apack, float* __restrict__ cvec) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)Lp * DP) return;
+  const int c = (int)(e & 3);
+  const int lane = (int)((e >> 2) & 63);
+  const int64_t tq = e >> 8;
+  const int q = (int)(tq % (DP / 8));
+  const int t = (int)(tq / (DP / 8));
+  const int leaf = 32 * t + (lane & 31);
+  const int dim = 8 * q + 4 * (lane >> 5) + c;
+  float v = 0.f;
+  if (leaf < L && dim < D) v = (float)alpha[(int64_t)node_of_leaf[leaf] * D + dim];
+  apack[e] = v;
+  if (dim == 0) {
+    double aa = 0.0;
+    if (leaf < L) {
+      const double* a = alpha + (int64_t)node_of_leaf[leaf] * D;
+      for (int d = 0; d < D; ++d) {
+        const double f = (double)(float)a[d];
+        aa += f * f;
+      }
+    }
+    cvec[leaf] = (float)(-0.5 * aa);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streamed regime, pass B: combine the partials of a frame, normalise its row in place,
+// accumulate S0' / S2.  One wave per row at a time, lanes stride the row in float4.
+// ------------------------------------------------------------------------------------------
+template <bool HARD>
+__global__ __launch_bounds__(256) void estep_normalize_kernel(
+    float* __restrict__ phi, float* __restrict__ logphi, int32_t* __restrict__ assign,
+    const float2* __restrict__ part, int nchunk, const float* __restrict__ prior,
+    const int32_t* __restrict__ vid, int64_t N, int L, int Lp, float inv_half_sz,
+    double* __restrict__ estats /* [L][2] atomically accumulated, or null */) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* st = reinterpret_cast<float*>(smem_raw);        // [Lp][2] fp32 partials of this block
+  const bool want_stats = estats != nullptr;
+  if (want_stats) {
+    for (int e = threadIdx.x; e < 2 * Lp; e += blockDim.x) st[e] = 0.f;
+    __syncthreads();
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int nw = blockDim.x >> 6;
+  for (int64_t n = (int64_t)blockIdx.x * nw + wave; n < N; n += (int64_t)gridDim.x * nw) {
+    // combine partials (every lane redundantly walks a strided share, then wave-reduces)
+    float m = -INFINITY;
+    int best = 0x7fffffff;
+    for (int c = lane; c < nchunk; c += 64) {
+      const float2 p = part[n * nchunk + c];
+      const int b = __float_as_int(p.y);
+      if (p.x > m || (HARD && p.x == m && b < best)) {
+        m = p.x;
+        best = b;
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float om = __shfl_xor(m, off);
+      const int ob = __shfl_xor(best, off);
+      if (om > m || (HARD && om == m && ob < best)) {
+        m = om;
+        best = ob;
+      }
+    }
+    float lse = 0.f;
+    if (!HARD) {
+      float ssum = 0.f;
+      for (int c = lane; c < nchunk; c += 64) {
+        const float2 p = part[n * nchunk + c];
+        if (p.x != -INFINITY) ssum += p.y * __builtin_amdgcn_exp2f((p.x - m) * kLog2e);
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) ssum += __shfl_xor(ssum, off);
+      lse = __builtin_amdgcn_logf(ssum) * kLn2;
+    }
+    float* row = phi + n * Lp;
+    float* lrow = logphi ? logphi + n * Lp : nullptr;
+    const float* prow = HARD ? nullptr : prior + (int64_t)vid[n] * Lp;
+    int amax = 0x7fffffff;
+    float vmax = -INFINITY;
+    for (int c4 = lane * 4; c4 < Lp; c4 += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(row + c4);
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+      float pv[4], lv[4];
+      float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!HARD) pr = *reinterpret_cast<const float4*>(prow + c4);
+      const float prv[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (HARD) {
+          pv[c] = (c4 + c == best) ? 1.f : 0.f;
+          lv[c] = (c4 + c == best) ? 0.f : -INFINITY;
+        } else {
+          lv[c] = (xv[c] - m) - lse;
+          pv[c] = __builtin_amdgcn_exp2f(lv[c] * kLog2e);
+          if (xv[c] > vmax) {
+            vmax = xv[c];
+            amax = c4 + c;
+          }
+        }
+        if (want_stats && c4 + c < L) {
+          float dd;
+          if (HARD)
+            dd = -xv[c];                                   // logit was -d^2
+          else {
+            const float d = (prv[c] - xv[c]) * inv_half_sz;  // logit = prior - half_sz*d
+            dd = d * d;
+          }
+          if (pv[c] != 0.f) {
+            atomicAdd(&st[2 * (c4 + c)], pv[c]);
+            atomicAdd(&st[2 * (c4 + c) + 1], pv[c] * dd);
+          }
+        }
+      }
+      *reinterpret_cast<float4*>(row + c4) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      if (lrow) *reinterpret_cast<float4*>(lrow + c4) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+    }
+    if (assign) {
+      if (HARD) {
+        if (lane == 0) assign[n] = best;
+      } else {
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const float om = __shfl_xor(vmax, off);
+          const int ob = __shfl_xor(amax, off);
+          if (om > vmax || (om == vmax && ob < amax)) {
+            vmax = om;
+            amax = ob;
+          }
+        }
+        if (lane == 0) assign[n] = amax;
+      }
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * L; e += blockDim.x)
+      if (st[e] != 0.f) atomicAdd(&estats[e], (double)st[e]);
+  }
+}
+
+__global__ void eslab_reduce_kernel(const double* __restrict__ slab, int nslab, int elems,
+                                    double* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  double s = 0.0;
+  for (int g = 0; g < nslab; ++g) s += slab[(int64_t)g * elems + e];
+  out[e] = s;
+}
+
+int estep_reduce_slabs(const EstepArgs& a, const double* eslab, int nslab) {
+  const int elems = 2 * a.tree->L;
+  hipLaunchKernelGGL(eslab_reduce_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, a.stream,
+                     eslab, nslab, elems, a.estats);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {
+  const int L = a.tree->L, Lp = a.tree->Lp;
+  if (a.estats) BNPVI_HIP(hipMemsetAsync(a.estats, 0, (size_t)2 * L * sizeof(double), a.stream));
+  int64_t nb = ceil_div(a.N, 4);
+  const int64_t capb = (int64_t)a.ctx->num_cu * 8;
+  if (nb > capb) nb = capb;
+  const size_t lds = a.estats ? (size_t)Lp * 8 : 0;
+  BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "estep: L=%d too large for the stats epilogue", L);
+  if (a.mode == BNPVI_ESTEP_HARD) {
+    auto k = estep_normalize_kernel<true>;
+    if (lds > 48 * 1024)
+      BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, a.stream, a.phi, a.logphi, a.assign, part,
+                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, a.estats);
+  } else {
+    auto k = estep_normalize_kernel<false>;
+    if (lds > 48 * 1024)
+      BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, a.stream, a.phi, a.logphi, a.assign, part,
+                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, a.estats);
+  }
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+template <> int estep_dispatch<8>(const EstepArgs&);
+template <> int estep_dispatch<16>(const EstepArgs&);
+template <> int estep_dispatch<32>(const EstepArgs&);
+template <> int estep_dispatch<64>(const EstepArgs&);
+template <> int estep_dispatch<128>(const EstepArgs&);
+template <> int estep_dispatch<256>(const EstepArgs&);
+
+int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
+                 const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
+                 double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
+                 hipStream_t s) {
+  const int DP = bnpvi_padded_dim(D);
+  // the streamed regime reads whole chunks of the packed operands: pad to 4 tiles
+  const int LpPack = round_up(t->Lp, 128);
+  int rc = ctx->pack.ensure(((size_t)LpPack * DP + LpPack) * sizeof(float));
+  if (rc) return rc;
+  float* apack = (float*)ctx->pack.ptr;
+  float* cvec = apack + (size_t)LpPack * DP;
+  {
+    const int64_t work = (int64_t)LpPack * DP;
+    hipLaunchKernelGGL(pack_leaves_kernel, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, s, alpha,
+                       D, DP, t->d_node_of_leaf, t->L, LpPack, apack, cvec);
+    BNPVI_LAUNCH_CHECK();
+  }
+  if (N == 0) {
+    if (estats) BNPVI_HIP(hipMemsetAsync(estats, 0, (size_t)2 * t->L * sizeof(double), s));
+    return BNPVI_OK;
+  }
+  EstepArgs a{ctx, t, Z, ldz, vid, N, apack, cvec, prior, (float)(0.5 * sZ), mode,
+              phi, logphi, assign, estats, s};
+  switch (DP) {
+    case 8: return estep_dispatch<8>(a);
+    case 16: return estep_dispatch<16>(a);
+    case 32: return estep_dispatch<32>(a);
+    case 64: return estep_dispatch<64>(a);
+    case 128: return estep_dispatch<128>(a);
+    case 256: return estep_dispatch<256>(a);
+  }
+  set_error("estep: unsupported padded dim %d", DP);
+  return BNPVI_EUNSUPPORTED;
+}
+
+}  // namespace bnpvi

@@ -1,0 +1,438 @@
+// Small per-node / per-video kernels of the VI step on the flattened tree (gfx950):
+//   node parameter update     /root/reference/src/var_inf.py:265-297
+//   gamma (stick) update      /root/reference/src/var_inf.py:395-416
+//   stick log-prior table     /root/reference/src/var_inf.py:303-311, 359-381
+//   weighted k-means seeding  /root/reference/src/var_inf.py:23-36
+//   phi column surgery        /root/reference/src/var_inf.py:196, 232
+// All of this is fp64 (the reference is NumPy fp64) except where noted; none of it is on the
+// N*L*D critical path, so the kernels favour exactness and simplicity.
+#include <math.h>
+
+#include "common.h"
+
+namespace bnpvi {
+
+// ------------------------------------------------------------------------------------------
+// Node parameters: one launch per tree level, deepest level first.  A node at depth d reads
+// alpha[parent] (depth d-1, not yet rewritten => the OLD value, as in the reference's
+// post-order recursion) and alpha[children] (depth d+1, already rewritten => NEW values).
+// ------------------------------------------------------------------------------------------
+__global__ void node_params_level_kernel(const int32_t* __restrict__ level_nodes, int count,
+                                         const int32_t* __restrict__ parent,
+                                         const int32_t* __restrict__ leaf_of_node,
+                                         const int32_t* __restrict__ child_ptr,
+                                         const int32_t* __restrict__ child_idx,
+                                         const double* __restrict__ stats, int W, int D, double sB,
+                                         double sZ, const double* __restrict__ alpha0,
+                                         double* alpha, double* __restrict__ sigma) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)count * D) return;
+  const int k = level_nodes[e / D];
+  const int d = (int)(e % D);
+  const int p = parent[k];
+  const double base = (p < 0) ? (alpha0 ? alpha0[d] : 0.0) : alpha[(int64_t)p * D + d];
+  const int l = leaf_of_node[k];
+  double s, a;
+  if (l >= 0) {
+    const double S0 = stats[(int64_t)l * W];
+    const double S1 = stats[(int64_t)l * W + 1 + d];
+    s = sB + S0 * sZ;
+    a = (base * sB + S1 * sZ) / s;
+  } else {
+    const int c0 = child_ptr[k], c1 = child_ptr[k + 1];
+    s = (1.0 + (double)(c1 - c0)) * sB;
+    double acc = base;
+    for (int c = c0; c < c1; ++c) acc += alpha[(int64_t)child_idx[c] * D + d];
+    a = acc * sB / s;
+  }
+  alpha[(int64_t)k * D + d] = a;
+  if (d == 0) sigma[k] = s;
+}
+
+int launch_node_params(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D,
+                       double sB, double sZ, const double* alpha0, double* alpha, double* sigma,
+                       hipStream_t s) {
+  (void)ctx;
+  for (int lev = t->nlevels - 1; lev >= 0; --lev) {
+    const int off = t->level_ptr[lev];
+    const int count = t->level_ptr[lev + 1] - off;
+    if (count == 0) continue;
+    const int64_t work = (int64_t)count * D;
+    hipLaunchKernelGGL(node_params_level_kernel, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, s,
+                       t->d_level_nodes + off, count, t->d_parent, t->d_leaf_of_node, t->d_child_ptr,
+                       t->d_child_idx, stats, W, D, sB, sZ, alpha0, alpha, sigma);
+    BNPVI_LAUNCH_CHECK();
+  }
+  return BNPVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// In-place inclusive scan of a[0..n) (fp64, LDS) by one workgroup.  tmp: blockDim.x doubles.
+// ------------------------------------------------------------------------------------------
+__device__ void block_inclusive_scan(double* a, int n, double* tmp) {
+  const int T = blockDim.x, t = threadIdx.x;
+  const int seg = (n + T - 1) / T;
+  const int b = t * seg, e = (b + seg < n) ? b + seg : n;
+  double run = 0.0;
+  for (int j = b; j < e; ++j) {
+    run += a[j];
+    a[j] = run;
+  }
+  tmp[t] = run;
+  __syncthreads();
+  for (int off = 1; off < T; off <<= 1) {
+    double v = (t >= off) ? tmp[t - off] : 0.0;
+    __syncthreads();
+    tmp[t] += v;
+    __syncthreads();
+  }
+  const double add = (t > 0) ? tmp[t - 1] : 0.0;
+  for (int j = b; j < e; ++j) a[j] += add;
+  __syncthreads();
+}
+
+// gamma[v][k] = (1 + mass of k's leaves, GAMMA + mass of all leaves before k's first leaf).
+// The reference's recursion (src/var_inf.py:395-413) hands every child "before(parent) + mass
+// of earlier siblings"; with leaves in DFS order that is the exclusive prefix at leaf_lo[k].
+__global__ void gamma_kernel(const double* __restrict__ mass, int L, int K,
+                             const int32_t* __restrict__ leaf_lo,
+                             const int32_t* __restrict__ leaf_hi, double gamma_hyper,
+                             double* __restrict__ gamma) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* P = reinterpret_cast<double*>(smem_raw);   // [L] inclusive prefix
+  double* tmp = P + L;                               // [blockDim.x]
+  const int v = blockIdx.x;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) P[l] = mass[(int64_t)v * L + l];
+  __syncthreads();
+  block_inclusive_scan(P, L, tmp);
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    const int lo = leaf_lo[k], hi = leaf_hi[k];
+    const double before = lo > 0 ? P[lo - 1] : 0.0;
+    const double upto = hi > 0 ? P[hi - 1] : 0.0;
+    double2 g;
+    g.x = 1.0 + (upto - before);
+    g.y = gamma_hyper + before;
+    reinterpret_cast<double2*>(gamma)[(int64_t)v * K + k] = g;
+  }
+}
+
+int launch_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, int V,
+                        double gamma_hyper, double* gamma, hipStream_t s) {
+  (void)ctx;
+  const int T = 256;
+  const size_t lds = (size_t)(t->L + T) * sizeof(double);
+  BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "gamma_update: L=%d too large for LDS", t->L);
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(gamma_kernel, dim3(V), dim3(T), lds, s, mass, t->L, t->K, t->d_leaf_lo,
+                     t->d_leaf_hi, gamma_hyper, gamma);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// digamma for x >= 1 (arguments here are 1+mass, GAMMA+mass and their sum): upward recurrence
+// to x >= 10, then the asymptotic series through x^-14 (truncation < 5e-17).
+// ------------------------------------------------------------------------------------------
+__device__ double digamma_pos(double x) {
+  double r = 0.0;
+  while (x < 10.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double f = 1.0 / (x * x);
+  const double t =
+      f * (-1.0 / 12.0 +
+           f * (1.0 / 120.0 +
+                f * (-1.0 / 252.0 +
+                     f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
+  return r + log(x) - 0.5 / x + t;
+}
+
+// One workgroup per video.  e0[k] = psi(g0)-psi(g0+g1), e1[k] = psi(g1)-psi(g0+g1), root = 0.
+//   on[l]     = sum of e0 over the path root->l (root excluded)          (src/var_inf.py:359-368)
+//   before[l] = sum of e1 over all non-root nodes that precede l in pre-order and are not
+//               ancestors of l                                           (src/var_inf.py:370-381)
+//             = P[node(l)-1] - sum_{ancestors a} e1[a],  P = inclusive pre-order prefix of e1.
+__global__ void prior_kernel(const double* __restrict__ gamma, const double* __restrict__ sigma,
+                             const int32_t* __restrict__ parent,
+                             const int32_t* __restrict__ node_of_leaf, int K, int L, int Lp,
+                             double half_sz, float* __restrict__ prior, double* __restrict__ on_out,
+                             double* __restrict__ before_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* e0 = reinterpret_cast<double*>(smem_raw);   // [K]
+  double* P = e0 + K;                                 // [K]
+  double* tmp = P + K;                                // [blockDim.x]
+  const int v = blockIdx.x;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    if (k == 0) {
+      e0[0] = 0.0;
+      P[0] = 0.0;
+    } else {
+      const double2 g = reinterpret_cast<const double2*>(gamma)[(int64_t)v * K + k];
+      const double ps = digamma_pos(g.x + g.y);
+      e0[k] = digamma_pos(g.x) - ps;
+      P[k] = digamma_pos(g.y) - ps;
+    }
+  }
+  __syncthreads();
+  block_inclusive_scan(P, K, tmp);
+
+  double best = -INFINITY;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int l = threadIdx.x; l < Lp; l += blockDim.x) {
+      if (l >= L) {
+        if (pass == 1) prior[(int64_t)v * Lp + l] = -INFINITY;
+        continue;
+      }
+      const int k = node_of_leaf[l];
+      double on = 0.0, anc = 0.0;
+      if (k > 0) {
+        on = e0[k];
+        int a = parent[k];
+        while (a > 0) {
+          on += e0[a];
+          anc += P[a] - P[a - 1];
+          a = parent[a];
+        }
+      }
+      const double before = (k > 0 ? P[k - 1] : 0.0) - anc;
+      const double val = on + before - half_sz / sigma[k];
+      if (pass == 0) {
+        best = fmax(best, val);
+      } else {
+        prior[(int64_t)v * Lp + l] = (float)(val - best);
+        if (on_out) on_out[(int64_t)v * L + l] = on;
+        if (before_out) before_out[(int64_t)v * L + l] = before;
+      }
+    }
+    if (pass == 0) {
+      __syncthreads();
+      tmp[threadIdx.x] = best;
+      __syncthreads();
+      for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) tmp[threadIdx.x] = fmax(tmp[threadIdx.x], tmp[threadIdx.x + off]);
+        __syncthreads();
+      }
+      best = tmp[0];
+      __syncthreads();
+    }
+  }
+}
+
+int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
+                       const double* sigma, int V, double sZ, float* prior, double* on,
+                       double* before, hipStream_t s) {
+  (void)ctx;
+  const int T = 256;
+  const size_t lds = (size_t)(2 * t->K + T) * sizeof(double);
+  BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "prior_table: K=%d too large for LDS (max ~10000)", t->K);
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)prior_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(prior_kernel, dim3(V), dim3(T), lds, s, gamma, sigma, t->d_parent,
+                     t->d_node_of_leaf, t->K, t->L, t->Lp, 0.5 * sZ, prior, on, before);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Weighted farthest-point seeding pass (src/var_inf.py:31-35): G lanes per row, float4 loads.
+// ------------------------------------------------------------------------------------------
+struct Best {
+  float score;
+  long long row;
+};
+
+__device__ inline bool better(float s, long long r, float bs, long long br) {
+  return (s > bs) || (s == bs && r < br);   // np.argmax: first index wins ties
+}
+
+template <int G>   // lanes per row; row width handled = 4*G floats per step
+__global__ __launch_bounds__(256) void kmeans_pass_kernel(const float* __restrict__ Z, int ldz,
+                                                          int64_t N, int Dp,
+                                                          const float* __restrict__ w, int ldw,
+                                                          const float* __restrict__ center, int first,
+                                                          float* __restrict__ dist2,
+                                                          Best* __restrict__ partial) {
+  __shared__ Best sh[256];
+  const int g = threadIdx.x % G;
+  const int64_t rows_per_block = 256 / G;
+  Best mine;
+  mine.score = -1.f;
+  mine.row = 0x7fffffffffffffffLL;
+  for (int64_t n = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / G; n < N;
+       n += (int64_t)gridDim.x * rows_per_block) {
+    float d2 = 0.f;
+    if (center != nullptr) {
+      for (int c = g * 4; c < Dp; c += 4 * G) {
+        const float4 z = *reinterpret_cast<const float4*>(Z + n * ldz + c);
+        const float4 m = *reinterpret_cast<const float4*>(center + c);
+        const float dx = z.x - m.x, dy = z.y - m.y, dz = z.z - m.z, dw = z.w - m.w;
+        d2 += dx * dx + dy * dy + dz * dz + dw * dw;
+      }
+#pragma unroll
+      for (int off = G >> 1; off > 0; off >>= 1) d2 += __shfl_xor(d2, off);
+    }
+    if (g == 0) {
+      float score;
+      const float wn = w[n * ldw];
+      if (center == nullptr) {
+        score = wn;
+      } else {
+        const float dm = first ? d2 : fminf(dist2[n], d2);
+        dist2[n] = dm;
+        score = wn * __builtin_amdgcn_sqrtf(dm);
+      }
+      if (better(score, n, mine.score, mine.row)) {
+        mine.score = score;
+        mine.row = n;
+      }
+    }
+  }
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const Best o = sh[threadIdx.x + off];
+      if (better(o.score, o.row, sh[threadIdx.x].score, sh[threadIdx.x].row)) sh[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ void kmeans_final_kernel(const Best* __restrict__ partial, int n,
+                                    int64_t* __restrict__ best_row, float* __restrict__ best_score) {
+  __shared__ Best sh[256];
+  Best mine;
+  mine.score = -1.f;
+  mine.row = 0x7fffffffffffffffLL;
+  for (int j = threadIdx.x; j < n; j += blockDim.x)
+    if (better(partial[j].score, partial[j].row, mine.score, mine.row)) mine = partial[j];
+  sh[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const Best o = sh[threadIdx.x + off];
+      if (better(o.score, o.row, sh[threadIdx.x].score, sh[threadIdx.x].row)) sh[threadIdx.x] = o;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // all scores 0 (e.g. all weights 0): normalize() falls back to uniform => index 0
+    *best_row = (sh[0].score > 0.f) ? sh[0].row : 0;
+    *best_score = sh[0].score;
+  }
+}
+
+int launch_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* w,
+                       int ldw, const float* center, int first, float* dist2, int64_t* best_row,
+                       float* best_score, hipStream_t s) {
+  const int Dp = bnpvi_padded_dim(D);
+  const int G = Dp / 4 < 64 ? Dp / 4 : 64;   // 2..64, power of two
+  const int64_t rows_per_block = 256 / G;
+  int64_t blocks = ceil_div(N, rows_per_block);
+  const int64_t cap = (int64_t)ctx->num_cu * 8;
+  if (blocks > cap) blocks = cap;
+  int rc = ctx->red.ensure((size_t)blocks * sizeof(Best));
+  if (rc) return rc;
+  Best* part = (Best*)ctx->red.ptr;
+#define KM(GG)                                                                                   \
+  hipLaunchKernelGGL(kmeans_pass_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, Z, ldz, N, \
+                     Dp, w, ldw, center, first, dist2, part)
+  switch (G) {
+    case 2: KM(2); break;
+    case 4: KM(4); break;
+    case 8: KM(8); break;
+    case 16: KM(16); break;
+    case 32: KM(32); break;
+    default: KM(64); break;
+  }
+#undef KM
+  BNPVI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kmeans_final_kernel, dim3(1), dim3(256), 0, s, part, (int)blocks, best_row,
+                     best_score);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// out[n][j] = scale[j] * in[n][src[j]]  (split: phi_parent/num_splits; merge: drop columns)
+// ------------------------------------------------------------------------------------------
+__global__ void remap_columns_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
+                                     int ld_out, int64_t N, const int32_t* __restrict__ src,
+                                     const float* __restrict__ scale) {
+  const int64_t total = N * ld_out;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = e / ld_out;
+    const int j = (int)(e % ld_out);
+    const int sj = src[j];
+    out[e] = sj >= 0 ? scale[j] * in[n * ld_in + sj] : 0.f;
+  }
+}
+
+int launch_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out, int ld_out,
+                         int64_t N, int Lnew, const int32_t* src_host, const float* scale_host,
+                         hipStream_t s) {
+  int rc = ctx->cols.ensure((size_t)ld_out * 8);
+  if (rc) return rc;
+  std::vector<int32_t> src(ld_out, -1);
+  std::vector<float> scale(ld_out, 0.f);
+  for (int j = 0; j < Lnew; ++j) {
+    src[j] = src_host[j];
+    scale[j] = scale_host[j];
+  }
+  int32_t* dsrc = (int32_t*)ctx->cols.ptr;
+  float* dscale = (float*)((char*)ctx->cols.ptr + (size_t)ld_out * 4);
+  // pageable-host copies: the runtime stages them before returning, so the vectors may die
+  BNPVI_HIP(hipMemcpyAsync(dsrc, src.data(), (size_t)ld_out * 4, hipMemcpyHostToDevice, s));
+  BNPVI_HIP(hipMemcpyAsync(dscale, scale.data(), (size_t)ld_out * 4, hipMemcpyHostToDevice, s));
+  BNPVI_HIP(hipStreamSynchronize(s));
+  if (N == 0) return BNPVI_OK;
+  int64_t blocks = ceil_div(N * ld_out, 256);
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(remap_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, ld_in, out,
+                     ld_out, N, dsrc, dscale);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// gamma re-layout after tree surgery: out[v][k] = in[v][src[k]] or the default (1, GAMMA)
+// ------------------------------------------------------------------------------------------
+__global__ void gamma_remap_kernel(const double2* __restrict__ in, int K_old, double2* __restrict__ out,
+                                   int K_new, int V, const int32_t* __restrict__ src,
+                                   double gamma_hyper) {
+  const int64_t total = (int64_t)V * K_new;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = e / K_new;
+    const int k = (int)(e % K_new);
+    const int sk = src[k];
+    double2 g;
+    g.x = 1.0;
+    g.y = gamma_hyper;
+    if (sk >= 0) g = in[v * K_old + sk];
+    out[e] = g;
+  }
+}
+
+int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out, int K_new, int V,
+                       const int32_t* src_host, double gamma_hyper, hipStream_t s) {
+  int rc = ctx->cols.ensure((size_t)K_new * 4);
+  if (rc) return rc;
+  int32_t* dsrc = (int32_t*)ctx->cols.ptr;
+  BNPVI_HIP(hipMemcpyAsync(dsrc, src_host, (size_t)K_new * 4, hipMemcpyHostToDevice, s));
+  BNPVI_HIP(hipStreamSynchronize(s));
+  int64_t blocks = ceil_div((int64_t)V * K_new, 256);
+  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(gamma_remap_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const double2*)in,
+                     K_old, (double2*)out, K_new, V, dsrc, gamma_hyper);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+}  // namespace bnpvi

@@ -1,0 +1,167 @@
+/*
+ * bnpvi.h -- C ABI of the MI355X-native (gfx950) variational-inference step of bnp-vae.
+ *
+ * One shared library (libbnpvi.so, built from bnp_vae_amd/csrc/ by hipcc) exports exactly the
+ * entry points below.  They are what the Python drop-in `bnp_vae_amd.var_inf.VarInf` binds
+ * through ctypes (bnp_vae_amd/_lib.py), and what any other host (C, C++, a cgo/JNI stub)
+ * would bind: plain pointers and sizes, no torch types.  The reference has no FFI of its
+ * own (it is NumPy); each entry point cites the reference routine whose
+ * data pass it replaces as /root/reference/src/<file>:<lines>.
+ *
+ * Conventions
+ *   - every function returns 0 (BNPVI_OK) or a BNPVI_E* code; bnpvi_last_error() gives a
+ *     thread-local message for the last failure.
+ *   - pointers named *_dev are DEVICE pointers owned by the caller (hipMalloc / torch);
+ *     *_host are host pointers.  `stream` is a hipStream_t passed as void* (NULL = default
+ *     stream).  Calls only enqueue work; results are ready after the stream is synchronised.
+ *   - latents Z: float32, row-major, one row per frame, frames of one video contiguous
+ *     (src/var_inf.py:72-82), row stride ldz >= bnpvi_padded_dim(D) with columns
+ *     D..padded-1 ZERO.
+ *   - responsibilities phi: float32, row-major [N][ldphi], ldphi = bnpvi_padded_leaves(L),
+ *     column j = j-th leaf in depth-first order (the order every reference recursion visits
+ *     leaves); padded columns hold 0.
+ *   - vid: int32 [N], index of the frame's video in [0, V) (src/var_inf.py:318-322 does
+ *     this lookup with list.index per frame).
+ *   - nodes are numbered in PRE-ORDER (the order of get_nodes_list, src/var_inf.py:465-472).
+ */
+#ifndef BNPVI_H
+#define BNPVI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BNPVI_ABI_VERSION 1
+
+enum {
+  BNPVI_OK = 0,
+  BNPVI_EINVAL = 1,       /* bad argument / shape the kernels do not support */
+  BNPVI_EHIP = 2,         /* a HIP runtime call failed */
+  BNPVI_ENOMEM = 3,
+  BNPVI_EUNSUPPORTED = 4
+};
+
+/* E-step modes */
+enum {
+  BNPVI_ESTEP_SOFT = 0,   /* softmax responsibilities, src/var_inf.py:313-357,383-393 */
+  BNPVI_ESTEP_HARD = 1    /* one-hot nearest leaf, src/var_inf.py:126-132 (first-call init);
+                             same rule as compute_acc_frame_avg_dynamic.py:49-52 */
+};
+
+typedef struct bnpvi_ctx bnpvi_ctx;     /* per-device workspace (partial-sum slabs, scratch) */
+typedef struct bnpvi_tree bnpvi_tree;   /* flattened Node hierarchy on the device (SoA) */
+
+int bnpvi_abi_version(void);
+const char* bnpvi_last_error(void);
+
+/* D padded to what the MFMA k-loop consumes; L padded to a whole 32-leaf MFMA tile. */
+int bnpvi_padded_dim(int D);
+int bnpvi_padded_leaves(int L);
+
+/* ---- context ----------------------------------------------------------------------- */
+int bnpvi_ctx_create(int device, bnpvi_ctx** out);
+int bnpvi_ctx_destroy(bnpvi_ctx* ctx);
+
+/* ---- tree: replaces the Node object graph of src/node.py:6-17 on the device ----------
+ * parent_host[k] = pre-order index of node k's parent (-1 for the root, k=0);
+ * is_leaf_host[k] = Node.isLeafNode.  Children order = order of appearance in pre-order
+ * (= Node.children order).  Derived arrays (depth, DFS leaf numbering, leaf ranges
+ * [lo,hi) per node, children CSR, level lists) are built here and uploaded. */
+int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent_host,
+                      const uint8_t* is_leaf_host, bnpvi_tree** out);
+int bnpvi_tree_destroy(bnpvi_tree* tree);
+int bnpvi_tree_num_leaves(const bnpvi_tree* tree);
+/* copies the pre-order index of every leaf (DFS leaf order) into out_host[L] */
+int bnpvi_tree_leaf_nodes(const bnpvi_tree* tree, int32_t* out_host);
+
+/* ---- M-step data pass: responsibility-weighted sufficient statistics ------------------
+ * Replaces the per-leaf NumPy passes of compute_sigma_node / compute_alpha_node
+ * (src/var_inf.py:265-297: sum(phi), sum(phi*Z)) and the per-video sums of
+ * compute_gamma_node (src/var_inf.py:400-403).
+ *   stats_dev  : double [L][W], W = 1 + D (+ D when want_q):  [S0 | S1[0..D) | Q[0..D)]
+ *                S0 = sum_n phi[n,l];  S1 = sum_n phi[n,l] z_n;  Q = sum_n phi[n,l] z_n^2
+ *                (Q feeds the split test, src/var_inf.py:219-220).  This is the buffer a
+ *                multi-GPU caller all-reduces (RCCL, sum, fp64) before bnpvi_node_params.
+ *   mass_dev   : double [V][L] or NULL:  m[v,l] = sum_{n in video v} phi[n,l]
+ * fp32 MFMA products, fp32 partial sums over <= 8192 frames, fp64 accumulation above that;
+ * partial slabs are combined in a fixed order (bit-reproducible run to run). */
+int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* phi_dev,
+                     int ldphi, const int32_t* vid_dev, int64_t N, int D, int L, int V,
+                     int want_q, double* stats_dev, double* mass_dev, void* stream);
+
+/* ---- M-step node update: src/var_inf.py:265-297 (post-order Gauss-Seidel) --------------
+ * sigma[k] : leaf  sB + sZ*S0 ; internal (1+#children)*sB
+ * alpha[k] : leaf  (alpha_old[parent]*sB + sZ*S1)/sigma ; internal
+ *            (alpha_old[parent or alpha0] + sum_children alpha_new)*sB/sigma
+ * alpha_dev: double [K][D] in/out (pre-order); sigma_dev: double [K] out;
+ * alpha0_dev: double [D] (ALPHA of src/util.py:23) or NULL for zeros. */
+int bnpvi_node_params(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* stats_dev,
+                      int stats_width, int D, double sigma_b_sqrinv, double sigma_z_sqrinv,
+                      const double* alpha0_dev, double* alpha_dev, double* sigma_dev,
+                      void* stream);
+
+/* ---- gamma-step: src/var_inf.py:395-416 ------------------------------------------------
+ * gamma_dev: double [V][K][2] out;  gamma0 = 1 + mass(subtree), gamma1 = GAMMA + mass of
+ * everything before the node among its ancestors' earlier siblings (prefix over DFS leaves).*/
+int bnpvi_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass_dev, int V,
+                       double gamma_hyper, double* gamma_dev, void* stream);
+
+/* ---- stick-breaking log-prior table: src/var_inf.py:303-311,359-381 --------------------
+ * prior_dev : float [V][ldp], ldp = bnpvi_padded_leaves(L).  Row v, column l holds
+ *             on[l][v] + before[l][v] - 0.5*sZ/sigma[leaf l]  minus the row maximum
+ *             (softmax over leaves is shift-invariant per frame; the shift is applied in
+ *             fp64 before rounding to fp32).  Padded columns hold -inf.
+ * on_dev / before_dev: optional double [V][L] unshifted tables (NULL to skip) -- the two
+ *             dicts compute_gamma_sum_on / compute_gamma_sum_before return. */
+int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamma_dev,
+                      const double* sigma_dev, int V, double sigma_z_sqrinv, float* prior_dev,
+                      double* on_dev, double* before_dev, void* stream);
+
+/* ---- E-step: src/var_inf.py:313-357,383-393 ---------------------------------------------
+ * logit[n,l] = prior[vid[n],l] - 0.5*sZ*||z_n - alpha_l||_2   (UN-squared norm)
+ * phi = softmax over leaves.  alpha_dev: double [K][D] (pre-order).
+ *   logphi_dev : float [N][ldphi] or NULL     (log responsibilities)
+ *   assign_dev : int32 [N] or NULL            (arg-max leaf, first index on ties)
+ *   estats_dev : double [L][2] or NULL        S0' = sum_n phi, S2 = sum_n phi*||z-alpha||^2
+ *                                             (mean(phi) and stdev of src/var_inf.py:194,217-220)
+ * mode BNPVI_ESTEP_HARD ignores prior and writes the one-hot nearest-leaf matrix. */
+int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int ldz,
+                const int32_t* vid_dev, int64_t N, int D, const double* alpha_dev,
+                const float* prior_dev, double sigma_z_sqrinv, int mode, float* phi_dev,
+                float* logphi_dev, int32_t* assign_dev, double* estats_dev, void* stream);
+
+/* ---- weighted farthest-point seeding pass: src/var_inf.py:23-36 -------------------------
+ * One pass per new centre.  dist2_dev[N] holds the running min squared distance to the
+ * centres chosen so far (ignored and overwritten when first != 0: the reference starts
+ * from a uniform 1/N).  Computes score[n] = w[n]*sqrt(min(dist2[n], ||z_n-c||^2)) for the
+ * centre `center_dev` (float [padded D] on the device, e.g. Z_dev + row*ldz; NULL for the
+ * initial arg-max of w alone),
+ * updates dist2, and writes the arg-max row (lowest index on ties) to *best_row_dev and its
+ * score to *best_score_dev.  w = phi column: w_dev + n*ldw. */
+int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z_dev, int ldz, int64_t N, int D,
+                      const float* w_dev, int ldw, const float* center_dev, int first,
+                      float* dist2_dev, int64_t* best_row_dev, float* best_score_dev,
+                      void* stream);
+
+/* ---- column surgery for split / merge: src/var_inf.py:196,232 ---------------------------
+ * out[n][j] = scale_host[j] * in[n][src_host[j]]  for j < Lnew; padded columns = 0.
+ * split: children take phi_parent/num_splits; merge: pruned leaves' columns are dropped
+ * (rows are NOT renormalised, as in the reference). */
+int bnpvi_remap_columns(bnpvi_ctx* ctx, const float* in_dev, int ld_in, float* out_dev,
+                        int ld_out, int64_t N, int Lnew, const int32_t* src_host,
+                        const float* scale_host, void* stream);
+
+/* ---- gamma re-layout after split / merge: src/node.py:15-16, src/var_inf.py:208 -----------
+ * out[v][k] = in[v][src_host[k]] for src_host[k] >= 0, else the Node.__init__ default
+ * (1, GAMMA) that a freshly split child carries until the next gamma-step; a node that
+ * absorbed its only child takes that child's gamma (deepcopy at src/var_inf.py:208). */
+int bnpvi_gamma_remap(bnpvi_ctx* ctx, const double* in_dev, int K_old, double* out_dev,
+                      int K_new, int V, const int32_t* src_host, double gamma_hyper,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BNPVI_H */

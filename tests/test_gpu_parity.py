@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the drop-in VarInf / DeviceVI)
+against the CPU oracle and the committed golden vectors (outputs of the real reference).
+
+Tolerances are BASELINE.json's: node parameters rel 1e-4, log-responsibilities abs 1e-4,
+hard assignments equal except at near-ties (|dlogp| < 1e-5).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle.vi_oracle import (OracleVarInf, ONode, snapshot, restore, make_latent_dict,
+                              gaussian_mixture, structure)
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PARAM_RTOL = 1e-4
+LOGP_ATOL = 1e-4
+PHI_ATOL = 1e-4
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name), allow_pickle=False))
+
+
+def sub(d, prefix):
+    return {k[len(prefix):]: v for k, v in d.items() if k.startswith(prefix)}
+
+
+def meta(d):
+    import json
+    return json.loads(str(d['meta']))
+
+
+def rows_for(fpv, N):
+    lc = make_latent_dict(np.zeros((N, 1), np.float32), list(fpv))
+    vids = list(lc.keys())
+    return vids, [(v, f) for v in vids for f in lc[v].keys()]
+
+
+def close_params(got, want, what):
+    scale = max(1.0, float(np.max(np.abs(want))))
+    np.testing.assert_allclose(got, want, rtol=PARAM_RTOL, atol=PARAM_RTOL * scale, err_msg=what)
+
+
+def assert_snap_close(got, want, phi_atol=PHI_ATOL):
+    assert list(got['ids']) == list(want['ids'])
+    np.testing.assert_array_equal(got['parent'], want['parent'])
+    np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
+    close_params(got['alpha'], want['alpha'], 'alpha')
+    close_params(got['sigma'], want['sigma'], 'sigma')
+    np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=PARAM_RTOL, atol=1e-3, equal_nan=True)
+    np.testing.assert_allclose(got['phi'], want['phi'], rtol=0, atol=phi_atol)
+
+
+def make_vi(**kw):
+    from bnp_vae_amd import VarInf
+    return VarInf(**kw)
+
+
+def product_from_snapshot(snap, D, thr, ns, fpv):
+    N = int(sum(fpv))
+    vids, pairs = rows_for(fpv, N)
+    vi = make_vi(latent_code_size=D, stdev_thr=thr, num_splits=ns)
+    vi.vidid_to_idx, vi.vidid_frameid_to_idx = list(vids), list(pairs)
+    restore(vi, snap, lambda nid, par: vi._new_node(nid, par), vids, pairs)
+    return vi
+
+
+def oracle_from_snapshot(snap, D, thr, ns, fpv):
+    N, V = int(sum(fpv)), len(fpv)
+    vids, pairs = rows_for(fpv, N)
+    vi = OracleVarInf(latent_code_size=D, stdev_thr=thr, num_splits=ns)
+    restore(vi, snap, lambda nid, par: ONode(nid, V, N, par, D, 10.0, rng=np.random.RandomState(0)),
+            vids, pairs)
+    return vi
+
+
+# --------------------------------------------------------------------------------------------
+def test_library_loads_on_gpu():
+    from bnp_vae_amd import _lib
+    assert _lib.lib.bnpvi_abi_version() == 1
+
+
+@pytest.mark.parametrize("name", ["phases_irregular.npz", "phases_ref_shape.npz"])
+def test_phases_against_golden(name):
+    g = load(name)
+    m = meta(g)
+    fpv = list(g['fpv'])
+    Z = g['Z']
+    vi = product_from_snapshot(sub(g, 'in_'), m['D'], m['thr'], m['num_splits'], fpv)
+    assert_snap_close(snapshot(vi), sub(g, 'in_'))
+
+    vi.compute_sigma_alpha(Z)                                    # M-step
+    s = snapshot(vi)
+    close_params(s['alpha'], g['m_alpha'], 'alpha after M-step')
+    close_params(s['sigma'], g['m_sigma'], 'sigma after M-step')
+
+    vi.compute_gamma()                                           # gamma-step
+    np.testing.assert_allclose(snapshot(vi)['gamma'], g['g_gamma'], rtol=PARAM_RTOL, atol=1e-4,
+                               equal_nan=True)
+
+    # prior tables (device digamma + prefix sums) from the device gamma
+    dev = vi._dev
+    vi._ensure_tree(); vi._sync_gamma()
+    on, before = dev.prior_table(want_tables=True)
+    np.testing.assert_allclose(on.cpu().numpy().T, g['on'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(before.cpu().numpy().T, g['before'], rtol=0, atol=2e-5)
+
+    logphi, assign = vi.compute_phi(Z, want_logphi=True, want_assign=True)   # E-step
+    L = g['logits'].shape[1]
+    lp = logphi.cpu().numpy()[:, :L]
+    np.testing.assert_allclose(lp, g['log_phi'], rtol=0, atol=LOGP_ATOL)
+    assert_snap_close(snapshot(vi), sub(g, 'e_'))
+    # hard assignments: equal except at near-ties
+    want = np.argmax(g['logits'], axis=1)
+    got = assign.cpu().numpy()
+    bad = np.nonzero(got != want)[0]
+    for i in bad:
+        assert abs(g['logits'][i, got[i]] - g['logits'][i, want[i]]) < 1e-5
+
+    # split diagnostics and decisions
+    S0, S2 = vi._leaf_moments()
+    N = Z.shape[0]
+    np.testing.assert_allclose(S0 / N, g['leaf_mean_phi'], rtol=1e-4, atol=1e-7)
+    heavy = g['leaf_mean_phi'] >= 1e-2
+    np.testing.assert_allclose(np.sqrt(np.sqrt(S2[heavy]) / S0[heavy]), g['leaf_stdev'][heavy], rtol=1e-4)
+    np.random.seed(0)
+    ret = vi.split_nodes(vi.root, Z, float(g['split_thr']))
+    assert bool(ret) == bool(g['split_ret'])
+    assert_snap_close(snapshot(vi), sub(g, 's_'))
+    vi.compute_phi(Z)
+    vi.merge_nodes(vi.root, Z, float(g['split_thr']))
+    assert_snap_close(snapshot(vi), sub(g, 'x_'))
+
+
+@pytest.mark.parametrize("name", ["traj_ref_shape.npz", "traj_dynamic.npz", "traj_single_video.npz"])
+def test_trajectory_against_golden(name):
+    """Several epochs of update_variational_parameters with a new Z each (drop-in flow)."""
+    g = load(name)
+    m = meta(g)
+    vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    for ep in range(m['epochs']):
+        lc = make_latent_dict(g['Z%d' % ep], list(g['fpv']))
+        np.random.seed(13 + ep)
+        vi.update_variational_parameters(lc)
+        want = sub(g, 'e%d_' % ep)
+        got = snapshot(vi)
+        assert_snap_close(got, want, phi_atol=2e-4)
+        assert float(got['decay']) == float(want['decay'])
+
+
+def test_weighted_kmeans_golden():
+    from bnp_vae_amd import VarInf
+    g = load("kmeans.npz")
+    for i in range(3):
+        c = VarInf.weighted_kmeans(g['data%d' % i], g['w%d' % i], int(g['K%d' % i]))
+        np.testing.assert_allclose(c, g['centers%d' % i], rtol=0, atol=0)
+
+
+def _regular_case(N, D, bf, levels, fpv, seed):
+    """Oracle + product on the same regular tree, one-hot init, same Z."""
+    Z = gaussian_mixture(N, D, bf ** levels, seed=seed, spread=4.0)
+    lc = make_latent_dict(Z, fpv)
+    np.random.seed(seed)
+    ora = OracleVarInf(latent_code_size=D, branching=bf, levels=levels, stdev_thr=1e9)
+    Zm = ora.get_matrix_from_dict(lc)
+    ora.build_initial_tree(); ora.build_video_index(); ora.one_hot_init(Zm)
+    np.random.seed(seed)
+    vi = make_vi(latent_code_size=D, branching=bf, levels=levels, stdev_thr=1e9)
+    Zp = vi.get_matrix_from_dict(lc)
+    vi._build_initial_tree(); vi._one_hot_init(Zp)
+    return ora, vi, Zm
+
+
+@pytest.mark.parametrize("N,D,bf,levels,fpv", [
+    (6000, 32, 5, 2, [256]),          # BASELINE config 1 shape (K=31), scaled N
+    (20000, 64, 8, 2, [256]),         # BASELINE config 2 shape (K=73, L=64)
+    (3000, 64, 8, 3, [100, 57]),      # BASELINE config 3 shape (K=585, L=512): streamed regime
+    (2500, 40, 3, 2, [300]),          # D not a kernel width (padded 40 -> 64), L=9
+    (4000, 128, 4, 3, [500]),         # reference tree shape, D=128
+])
+def test_iteration_against_oracle(N, D, bf, levels, fpv):
+    ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=7)
+    # one-hot init: identical except near-ties of the two nearest leaves
+    po, pp = snapshot(ora)['phi'], snapshot(vi)['phi']
+    mism = np.nonzero(np.argmax(po, 1) != np.argmax(pp, 1))[0]
+    assert len(mism) <= max(1, N // 2000), "one-hot init differs on %d frames" % len(mism)
+    if len(mism):
+        # continue from identical state
+        for leaf, col in zip(vi._dfs_leaves(), po.T):
+            leaf.phi = col.reshape(-1, 1)
+    for it in range(2):
+        ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
+        so, sp = snapshot(ora), snapshot(vi)
+        close_params(sp['alpha'], so['alpha'], 'alpha it%d' % it)
+        close_params(sp['sigma'], so['sigma'], 'sigma it%d' % it)
+        ora.compute_gamma(); vi.compute_gamma()
+        np.testing.assert_allclose(snapshot(vi)['gamma'], snapshot(ora)['gamma'], rtol=1e-4, atol=1e-4)
+        ora.compute_phi(Z)
+        logphi, assign = vi.compute_phi(Z, want_logphi=True, want_assign=True)
+        L = ora.last_log_phi.shape[1]
+        np.testing.assert_allclose(logphi.cpu().numpy()[:, :L], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
+        np.testing.assert_allclose(snapshot(vi)['phi'], snapshot(ora)['phi'], rtol=0, atol=PHI_ATOL)
+        got, want = assign.cpu().numpy(), np.argmax(ora.last_logits, axis=1)
+        for i in np.nonzero(got != want)[0]:
+            assert abs(ora.last_logits[i, got[i]] - ora.last_logits[i, want[i]]) < 1e-5
+        # size-independent properties
+        phi = snapshot(vi)['phi']
+        np.testing.assert_allclose(phi.sum(axis=1), 1.0, atol=1e-5)
+        S0, _ = vi._leaf_moments()
+        np.testing.assert_allclose(S0.sum(), N, rtol=1e-6)
+
+
+def test_frames_coinciding_with_leaf_means():
+    """Right after a split the new leaf means ARE data rows (weighted_kmeans): d = 0 exactly.
+    The fp32 expansion cancels catastrophically there; the kernel must fall back to direct
+    differences (kRefineRel path)."""
+    N, D, bf, levels = 2048, 64, 8, 2
+    ora, vi, Z = _regular_case(N, D, bf, levels, [256], seed=11)
+    rows = np.arange(0, 64) * 7
+    for vobj, leaves in ((ora, ora.leaves()), (vi, vi._dfs_leaves())):
+        for r, leaf in zip(rows, leaves):
+            leaf.alpha = Z[r].astype(np.float64)
+    ora.compute_phi(Z)
+    logphi, _ = vi.compute_phi(Z, want_logphi=True)
+    np.testing.assert_allclose(logphi.cpu().numpy()[:, :64], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
+
+
+def test_ragged_and_tiny_inputs():
+    """N not a multiple of the 32-frame tile, single-frame videos, a 2-frame data set."""
+    for N, fpv in ((33, [1, 2, 30]), (2, [1, 1]), (65, [64, 1])):
+        ora, vi, Z = _regular_case(N, 8, 2, 2, fpv, seed=3)
+        for leaf, col in zip(vi._dfs_leaves(), snapshot(ora)['phi'].T):
+            leaf.phi = col.reshape(-1, 1)
+        ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
+        ora.compute_gamma(); vi.compute_gamma()
+        ora.compute_phi(Z); vi.compute_phi(Z)
+        assert_snap_close(snapshot(vi), snapshot(ora))
+
+
+def test_pickle_and_writers(tmp_path):
+    import pickle
+    g = load("traj_dynamic.npz")
+    m = meta(g)
+    vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    np.random.seed(13)
+    vi.update_variational_parameters(make_latent_dict(g['Z0'], list(g['fpv'])))
+    vi.write_nodes(str(tmp_path / "nodes.pkl"))
+    vi.write_alpha(str(tmp_path / "alpha.txt"))
+    vi.write_sigma(str(tmp_path / "sigma.txt"))
+    with open(str(tmp_path / "nodes.pkl"), "rb") as f:
+        nodes = pickle.load(f)
+    assert [n.node_id for n in nodes] == list(g['e0_ids'])
+    root = [n for n in nodes if n.parent is None][0]
+    assert root.node_id == '0' and not root.isLeafNode
+    leaves = [n for n in nodes if n.isLeafNode]
+    np.testing.assert_allclose(np.concatenate([l.phi for l in leaves], axis=1), g['e0_phi'], atol=2e-4)
+    lines = (tmp_path / "alpha.txt").read_text().splitlines()
+    assert [l.split(' ')[0] for l in lines] == list(g['e0_ids'])
+    assert vi.get_true_path_mean([('a', 'b')] * 5).shape == (5, m['D'])
