@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbnpvi.so")
+LIB_PATH = os.environ.get("BNPVI_LIB") or os.path.join(_HERE, "libbnpvi.so")   # BNPVI_LIB: dev builds
 
 OK = 0
 ESTEP_SOFT = 0
@@ -26,6 +26,11 @@ def _load():
         raise ImportError(
             "bnp_vae_amd: %s is missing -- the gfx950 HIP library must be built first "
             "(make -C bnp_vae_amd/csrc); there is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and loads it
+    # by absolute path; if libbnpvi is loaded first it pulls in /opt/rocm's copy of the same
+    # SONAME and the second runtime to initialise reports "no ROCm-capable device".  Importing
+    # torch first makes the dynamic linker resolve libbnpvi's NEEDED entry to torch's copy.
+    import torch  # noqa: F401
     return C.CDLL(LIB_PATH)
 
 
@@ -44,6 +49,8 @@ EXPORTS = {
     "bnpvi_padded_leaves": (_i, [_i]),
     "bnpvi_ctx_create": (_i, [_i, C.POINTER(_p)]),
     "bnpvi_ctx_destroy": (_i, [_p]),
+    "bnpvi_profile_enable": (_i, [_p, _i]),
+    "bnpvi_profile_read": (_i, [_p, _i, C.POINTER(_d), C.POINTER(_i)]),
     "bnpvi_tree_create": (_i, [_p, _i, _p, _p, C.POINTER(_p)]),
     "bnpvi_tree_destroy": (_i, [_p]),
     "bnpvi_tree_num_leaves": (_i, [_p]),

@@ -40,6 +40,46 @@ void Scratch::release() {
   bytes = 0;
 }
 
+bool KernelTimer::begin(hipStream_t s) {
+  if (used >= kMax) return false;
+  if ((int)ev.size() < 2 * (used + 1)) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return false;
+    if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      return false;
+    }
+    ev.push_back(a);
+    ev.push_back(b);
+  }
+  return hipEventRecord(ev[2 * used], s) == hipSuccess;
+}
+
+void KernelTimer::end(hipStream_t s) {
+  (void)hipEventRecord(ev[2 * used + 1], s);
+  ++used;
+}
+
+int KernelTimer::read(double* total_ms, int* count) {
+  double tot = 0.0;
+  for (int i = 0; i < used; ++i) {
+    BNPVI_HIP(hipEventSynchronize(ev[2 * i + 1]));
+    float ms = 0.f;
+    BNPVI_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *count = used;
+  used = 0;
+  return BNPVI_OK;
+}
+
+void KernelTimer::release() {
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  ev.clear();
+  used = 0;
+}
+
 template <typename T>
 static int upload(const std::vector<T>& h, T** d) {
   size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
@@ -97,8 +137,25 @@ int bnpvi_ctx_destroy(bnpvi_ctx* ctx) {
   ctx->part.release();
   ctx->red.release();
   ctx->cols.release();
+  ctx->timer[0].release();
+  ctx->timer[1].release();
   delete ctx;
   return BNPVI_OK;
+}
+
+int bnpvi_profile_enable(bnpvi_ctx* ctx, int on) {
+  BNPVI_REQUIRE(ctx != nullptr, "bnpvi_profile_enable: ctx is NULL");
+  ctx->profiling = on != 0;
+  ctx->timer[0].used = ctx->timer[1].used = 0;
+  return BNPVI_OK;
+}
+
+int bnpvi_profile_read(bnpvi_ctx* ctx, int which, double* total_ms, int* count) {
+  BNPVI_REQUIRE(ctx && total_ms && count, "bnpvi_profile_read: NULL argument");
+  BNPVI_REQUIRE(which == BNPVI_PROF_ESTEP || which == BNPVI_PROF_MSTEP, "bnpvi_profile_read: which=%d",
+                which);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return ctx->timer[which].read(total_ms, count);
 }
 
 int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_t* is_leaf,

@@ -56,6 +56,18 @@ struct Scratch {
   void release();
 };
 
+// HIP-event timer for one kernel kind: events are recorded on the launch stream right around
+// the kernel (bench.py's roofline numbers come from here, see bnpvi_profile_read).
+struct KernelTimer {
+  static constexpr int kMax = 1024;
+  std::vector<hipEvent_t> ev;   // start/stop pairs
+  int used = 0;
+  bool begin(hipStream_t s);    // returns false when full or event creation failed
+  void end(hipStream_t s);
+  int read(double* total_ms, int* count);
+  void release();
+};
+
 }  // namespace bnpvi
 
 struct bnpvi_ctx {
@@ -66,6 +78,8 @@ struct bnpvi_ctx {
   bnpvi::Scratch part;       // per-frame softmax partials of the streamed E-step
   bnpvi::Scratch red;        // arg-max partials of the k-means pass
   bnpvi::Scratch cols;       // column maps of remap_columns
+  bnpvi::KernelTimer timer[2];   // BNPVI_PROF_ESTEP / BNPVI_PROF_MSTEP main kernels
+  bool profiling = false;
 };
 
 struct bnpvi_tree {
@@ -113,5 +127,9 @@ int launch_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out,
 
 int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out, int K_new, int V,
                        const int32_t* src_host, double gamma_hyper, hipStream_t s);
+
+// out[e] = sum_g slab[g][e], g ascending within 8 interleaved groups, groups combined in order
+// (fixed summation tree => bit-reproducible)
+int launch_slab_reduce(const double* slab, int nslab, int64_t elems, double* out, hipStream_t s);
 
 }  // namespace bnpvi

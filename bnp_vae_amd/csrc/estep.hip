@@ -154,21 +154,9 @@ __global__ __launch_bounds__(256) void estep_normalize_kernel(
   }
 }
 
-__global__ void eslab_reduce_kernel(const double* __restrict__ slab, int nslab, int elems,
-                                    double* __restrict__ out) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
-  double s = 0.0;
-  for (int g = 0; g < nslab; ++g) s += slab[(int64_t)g * elems + e];
-  out[e] = s;
-}
-
 int estep_reduce_slabs(const EstepArgs& a, const double* eslab, int nslab) {
   const int elems = 2 * a.tree->L;
-  hipLaunchKernelGGL(eslab_reduce_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, a.stream,
-                     eslab, nslab, elems, a.estats);
-  BNPVI_LAUNCH_CHECK();
-  return BNPVI_OK;
+  return launch_slab_reduce(eslab, nslab, elems, a.estats, a.stream);
 }
 
 int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {

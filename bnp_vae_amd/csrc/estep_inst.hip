@@ -23,13 +23,14 @@ static int run_fused(const EstepArgs& a) {
     eslab = (double*)a.ctx->slabs.ptr;
   }
   size_t lds = (size_t)NT * (DP / 8) * 64 * 16 + (size_t)Lp * 4 + (size_t)Lp * 16;
-  if (a.estats) lds += (size_t)kEWaves * NT * 32 * 64 * 4;
   BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "estep: LDS %zu too large", lds);
   auto k = a.estats ? estep_fused_kernel<DP, NT, true> : estep_fused_kernel<DP, NT, false>;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
   hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kEWaves * 64), lds, a.stream, a.Z, a.ldz, a.vid,
                      a.N, L, a.apack, a.cvec, a.prior, a.half_sz, a.phi, a.logphi, a.assign, eslab);
+  if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
   BNPVI_LAUNCH_CHECK();
   if (a.estats) return estep_reduce_slabs(a, eslab, (int)blocks);
   return BNPVI_OK;
@@ -51,6 +52,7 @@ static int run_streamed(const EstepArgs& a) {
   if (cap < 1) cap = 1;
   if (bx > cap) bx = cap;
   dim3 grid((unsigned)bx, (unsigned)nchunk);
+  const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
   if (a.mode == BNPVI_ESTEP_HARD)
     hipLaunchKernelGGL((estep_logits_kernel<DP, NT, true>), grid, dim3(kEWaves * 64), 0, a.stream, a.Z,
                        a.ldz, a.vid, a.N, a.tree->L, Lp, a.apack, a.cvec, a.prior, a.half_sz, a.phi,
@@ -59,6 +61,7 @@ static int run_streamed(const EstepArgs& a) {
     hipLaunchKernelGGL((estep_logits_kernel<DP, NT, false>), grid, dim3(kEWaves * 64), 0, a.stream, a.Z,
                        a.ldz, a.vid, a.N, a.tree->L, Lp, a.apack, a.cvec, a.prior, a.half_sz, a.phi,
                        part, nchunk);
+  if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
   BNPVI_LAUNCH_CHECK();
   return estep_finish_streamed(a, part, nchunk);
 }

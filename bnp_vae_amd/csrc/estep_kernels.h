@@ -62,7 +62,12 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   float zz = 0.f;
 #pragma unroll
   for (int q = 0; q < DP / 8; ++q) {
+#ifdef BNPVI_ABLATE_NOZLOAD
+    zreg[q] = make_float4(0.01f * lane, 0.02f * q, 0.5f, -0.25f);
+    (void)zrow;
+#else
     zreg[q] = *reinterpret_cast<const float4*>(zrow + 8 * q + 4 * h);
+#endif
     zz = fmaf(zreg[q].x, zreg[q].x, zz);
     zz = fmaf(zreg[q].y, zreg[q].y, zz);
     zz = fmaf(zreg[q].z, zreg[q].z, zz);
@@ -85,11 +90,15 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   for (int q = 0; q < DP / 8; ++q) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#ifdef BNPVI_ABLATE_NOMFMA
+      acc[t][q & 15] += zreg[q].x + zreg[q].y + zreg[q].z + zreg[q].w;
+#else
       const float4 a = a4[(t * (DP / 8) + q) * 64 + lane];
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zreg[q].x, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zreg[q].y, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zreg[q].z, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zreg[q].w, acc[t], 0, 0, 0);
+#endif
     }
   }
   // d^2 in place; remember which entries are too cancelled to trust
@@ -142,7 +151,7 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
 // written once (algorithmic traffic: read Z once, write phi once).
 // ------------------------------------------------------------------------------------------
 template <int DP, int NT, bool STATS>
-__global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void estep_fused_kernel(
+__global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2 && !STATS) ? 2 : 1) void estep_fused_kernel(
     const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L,
     const float* __restrict__ apack, const float* __restrict__ cvec,
     const float* __restrict__ prior, float half_sz, float* __restrict__ phi,
@@ -152,16 +161,11 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void e
   float4* a_lds = reinterpret_cast<float4*>(smem_raw);                  // [NT*(DP/8)*64]
   float* c_lds = reinterpret_cast<float*>(a_lds + NT * (DP / 8) * 64);  // [Lp]
   double* st_lds = reinterpret_cast<double*>(c_lds + Lp);               // [Lp][2]
-  // per-wave, per-lane fp32 accumulators of (phi, phi*d^2) for every logit register: kept in
-  // LDS (lane-private slots, conflict-free ds_add_f32) instead of 64 more VGPRs per lane
-  float* sacc = reinterpret_cast<float*>(st_lds + 2 * Lp);              // [waves][NT*16*2][64]
 
   for (int e = threadIdx.x; e < NT * (DP / 8) * 64; e += blockDim.x)
     a_lds[e] = reinterpret_cast<const float4*>(apack)[e];
   for (int e = threadIdx.x; e < Lp; e += blockDim.x) c_lds[e] = cvec[e];
   for (int e = threadIdx.x; e < 2 * Lp; e += blockDim.x) st_lds[e] = 0.0;
-  if (STATS)
-    for (int e = threadIdx.x; e < kEWaves * NT * 32 * 64; e += blockDim.x) sacc[e] = 0.f;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -169,7 +173,15 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void e
   const int j = lane & 31;
   const int h = lane >> 5;
   const int64_t ntiles = (N + 31) / 32;
-  float* my_sacc = sacc + (wave * NT * 32) * 64 + lane;
+  // per-lane fp32 accumulators of (phi, phi*d^2) per logit register (STATS only; LDS float
+  // atomics were tried instead and stalled the LDS pipe 4x: profiles/r01_notes.md)
+  float s0[STATS ? NT : 1][16], s2[STATS ? NT : 1][16];
+  if (STATS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[t][r] = s2[t][r] = 0.f;
+  }
 
   for (int64_t tile = (int64_t)blockIdx.x * kEWaves + wave; tile < ntiles;
        tile += (int64_t)gridDim.x * kEWaves) {
@@ -190,7 +202,12 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void e
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+#ifdef BNPVI_ABLATE_NOPRIOR
+        const float4 p4 = make_float4(0.f, 0.1f, 0.2f, 0.3f);
+        (void)prow;
+#else
         const float4 p4 = *reinterpret_cast<const float4*>(prow + 32 * t + 8 * g + 4 * h);
+#endif
         const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -236,11 +253,15 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void e
           lv[c] = lg[t][r] - lse;
           pv[c] = __builtin_amdgcn_exp2f(lv[c] * kLog2e);
           if (STATS && ok) {
-            atomicAdd(my_sacc + ((t * 16 + r) * 2) * 64, pv[c]);
-            atomicAdd(my_sacc + ((t * 16 + r) * 2 + 1) * 64, pv[c] * d2[t][r]);
+            s0[t][r] += pv[c];
+            s2[t][r] = fmaf(pv[c], d2[t][r], s2[t][r]);
           }
         }
+#ifdef BNPVI_ABLATE_NOSTORE
+        if (ok && pv[0] + pv[1] + pv[2] + pv[3] == -123.f) {
+#else
         if (ok) {
+#endif
           *reinterpret_cast<float4*>(prow_out + 32 * t + 8 * g + 4 * h) =
               make_float4(pv[0], pv[1], pv[2], pv[3]);
           if (lrow_out)
@@ -255,9 +276,11 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2) ? 2 : 1) void e
   if (STATS) {
     // reduce the per-lane leaf accumulators over the 32 frame lanes of each half-wave, then
     // fp64 accumulation in LDS, one slab per workgroup (summed in fixed order afterwards)
+#pragma unroll
     for (int t = 0; t < NT; ++t) {
+#pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float a = my_sacc[((t * 16 + r) * 2) * 64], b = my_sacc[((t * 16 + r) * 2 + 1) * 64];
+        float a = s0[t][r], b = s2[t][r];
 #pragma unroll
         for (int off = 1; off < 32; off <<= 1) {
           a += __shfl_xor(a, off);

@@ -175,15 +175,6 @@ __global__ __launch_bounds__(kStatWaves * 64) void leaf_stats_kernel(
   }
 }
 
-__global__ void slab_reduce_kernel(const double* __restrict__ slab, int nslab, int64_t elems,
-                                   double* __restrict__ out) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= elems) return;
-  double s = 0.0;
-  for (int g = 0; g < nslab; ++g) s += slab[(int64_t)g * elems + e];
-  out[e] = s;
-}
-
 template <int TL, int TD, bool Q>
 static int run_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
                      const int32_t* vid, int64_t N, int D, int Dp, int L, int W, double* stats,
@@ -207,14 +198,13 @@ static int run_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, 
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)gz);
+  const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
   hipLaunchKernelGGL(kern, grid, dim3(kStatWaves * 64), lds, s, Z, ldz, phi, ldphi, vid, N, D, Dp, L,
                      chunk, (double*)ctx->slabs.ptr, W, mass);
+  if (timed) ctx->timer[BNPVI_PROF_MSTEP].end(s);
   BNPVI_LAUNCH_CHECK();
   const int64_t elems = (int64_t)L * W;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(elems, 256)), dim3(256), 0, s,
-                     (const double*)ctx->slabs.ptr, (int)gx, elems, stats);
-  BNPVI_LAUNCH_CHECK();
-  return BNPVI_OK;
+  return launch_slab_reduce((const double*)ctx->slabs.ptr, (int)gx, elems, stats, s);
 }
 
 int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,

@@ -435,4 +435,44 @@ int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out,
   return BNPVI_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Fixed-order reduction of per-workgroup fp64 slabs: 32 outputs x 8 slab groups per block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int nslab,
+                                                          int64_t elems, double* __restrict__ out) {
+  __shared__ double sh[8][32];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int64_t e = (int64_t)blockIdx.x * 32 + lane;
+  double acc = 0.0;
+  if (e < elems) {
+    int g = grp;
+    for (; g + 24 < nslab; g += 32) {     // 4 independent loads in flight per thread
+      const double a0 = slab[(int64_t)g * elems + e];
+      const double a1 = slab[(int64_t)(g + 8) * elems + e];
+      const double a2 = slab[(int64_t)(g + 16) * elems + e];
+      const double a3 = slab[(int64_t)(g + 24) * elems + e];
+      acc += a0;
+      acc += a1;
+      acc += a2;
+      acc += a3;
+    }
+    for (; g < nslab; g += 8) acc += slab[(int64_t)g * elems + e];
+  }
+  sh[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && e < elems) {
+    double t = sh[0][lane];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sh[k][lane];
+    out[e] = t;
+  }
+}
+
+int launch_slab_reduce(const double* slab, int nslab, int64_t elems, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(256), 0, s, slab,
+                     nslab, elems, out);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
 }  // namespace bnpvi

@@ -153,6 +153,15 @@ int bnpvi_remap_columns(bnpvi_ctx* ctx, const float* in_dev, int ld_in, float* o
                         int ld_out, int64_t N, int Lnew, const int32_t* src_host,
                         const float* scale_host, void* stream);
 
+/* ---- measurement hooks (no reference counterpart; used by bench.py) ----------------------
+ * With profiling on, bnpvi_estep and bnpvi_leaf_stats record a HIP event pair on the launch
+ * stream right around their main kernel (the fused / logits E-step kernel, the R^T.Z stats
+ * kernel); bnpvi_profile_read waits for them, returns the summed kernel time and the number
+ * of launches since the last read, and resets the counter (at most 1024 launches are kept). */
+enum { BNPVI_PROF_ESTEP = 0, BNPVI_PROF_MSTEP = 1 };
+int bnpvi_profile_enable(bnpvi_ctx* ctx, int on);
+int bnpvi_profile_read(bnpvi_ctx* ctx, int which, double* total_ms, int* count);
+
 /* ---- gamma re-layout after split / merge: src/node.py:15-16, src/var_inf.py:208 -----------
  * out[v][k] = in[v][src_host[k]] for src_host[k] >= 0, else the Node.__init__ default
  * (1, GAMMA) that a freshly split child carries until the next gamma-step; a node that

@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Development micro-benchmark: times the individual C-ABI calls of one VI iteration with
+HIP events (torch events on the launch stream).  BNPVI_LIB=<path> selects an alternative
+build of the library (e.g. the ablation variants of `make -C bnp_vae_amd/csrc variants`)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=64)
+    ap.add_argument("--bf", type=int, default=8)
+    ap.add_argument("--levels", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    import torch
+    from bench import regular_tree, make_latents
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    dev = DeviceVI(device=0)
+    parent, is_leaf = regular_tree(args.bf, args.levels)
+    K, L = len(parent), int(is_leaf.sum())
+    Z, vid, V = make_latents(torch, dev.device, args.n, args.d, L, 0)
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, args.d)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    for _ in range(3):
+        dev.iteration(want_estats=False)
+    phases = [
+        ("leaf_stats", lambda: dev.leaf_stats(False, True)),
+        ("leaf_stats_q", lambda: dev.leaf_stats(True, True)),
+        ("node_params", dev.node_params),
+        ("gamma_update", dev.gamma_update),
+        ("prior_table", dev.prior_table),
+        ("estep", lambda: dev.estep(want_stats=False)),
+        ("estep_stats", lambda: dev.estep(want_stats=True)),
+        ("estep_logphi", lambda: dev.estep(want_stats=False, want_logphi=True)),
+        ("iteration", lambda: dev.iteration(want_estats=False)),
+    ]
+    out = []
+    for name, fn in phases:
+        fn()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.iters + 1)]
+        ev[0].record()
+        for i in range(args.iters):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
+        out.append("%s=%.1f" % (name, 1e3 * ts[len(ts) // 2]))
+    print("%s N=%d D=%d L=%d  [us median] %s" % (args.tag or os.environ.get("BNPVI_LIB", "default").split("_")[-1],
+                                                args.n, args.d, L, " ".join(out)))
+
+
+if __name__ == "__main__":
+    main()
