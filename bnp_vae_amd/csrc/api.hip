@@ -99,8 +99,8 @@ int bnpvi_abi_version(void) { return BNPVI_ABI_VERSION; }
 const char* bnpvi_last_error(void) { return g_err; }
 
 int bnpvi_padded_dim(int D) {
-  // the E-step k-loop is unrolled over whole registers: templates exist for these widths
-  const int sizes[] = {8, 16, 32, 64, 128, 256};
+  // the E-step K-loop consumes 32 dims per MFMA step: kernels are instantiated for these widths
+  const int sizes[] = {32, 64, 128, 256};
   for (int s : sizes)
     if (D <= s) return s;
   return -1;

@@ -6,34 +6,56 @@
 namespace bnpvi {
 
 // ------------------------------------------------------------------------------------------
-// pack leaf parameters: alpha (fp64, [K][D], pre-order) -> fp32 operand order; cvec = -|a|^2/2
+// Leaf operands.  Step 1 (one thread per padded leaf): fp32 row-major copy a32[Lp][DP] of the
+// leaves' alpha (fp64, [K][D], pre-order), ||alpha||^2 of the fp32-rounded values, and the
+// global max |alpha| (atomicMax on the bit pattern; non-negative floats order like ints).
+// Step 2 (one thread per 16-byte fragment): scaled exact hi/lo f16 split in MFMA operand
+// order: frag[((T*S+s)*2+part)*64+lane][e] = alpha[leaf 16T+(lane&15)][dim 32s+16(e>>2)+4(lane>>4)+(e&3)].
 // ------------------------------------------------------------------------------------------
-__global__ void pack_leaves_kernel(const double* __restrict__ alpha, int D, int DP,
-                                   const int32_t* __restrict__ node_of_leaf, int L, int Lp,
-                                   float* __restrict__ apack, float* __restrict__ cvec) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (int64_t)Lp * DP) return;
-  const int c = (int)(e & 3);
-  const int lane = (int)((e >> 2) & 63);
-  const int64_t tq = e >> 8;
-  const int q = (int)(tq % (DP / 8));
-  const int t = (int)(tq / (DP / 8));
-  const int leaf = 32 * t + (lane & 31);
-  const int dim = 8 * q + 4 * (lane >> 5) + c;
-  float v = 0.f;
-  if (leaf < L && dim < D) v = (float)alpha[(int64_t)node_of_leaf[leaf] * D + dim];
-  apack[e] = v;
-  if (dim == 0) {
-    double aa = 0.0;
-    if (leaf < L) {
-      const double* a = alpha + (int64_t)node_of_leaf[leaf] * D;
-      for (int d = 0; d < D; ++d) {
-        const double f = (double)(float)a[d];
-        aa += f * f;
-      }
-    }
-    cvec[leaf] = (float)(-0.5 * aa);
+__global__ void leaf_rows_kernel(const double* __restrict__ alpha, int D, int DP,
+                                 const int32_t* __restrict__ node_of_leaf, int L, int Lp,
+                                 float* __restrict__ a32, float* __restrict__ aavec,
+                                 int* __restrict__ amax_bits) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= Lp) return;
+  double aa = 0.0;
+  float amax = 0.f;
+  const double* a = leaf < L ? alpha + (int64_t)node_of_leaf[leaf] * D : nullptr;
+  for (int d = 0; d < DP; ++d) {
+    const float f = (a && d < D) ? (float)a[d] : 0.f;
+    a32[(int64_t)leaf * DP + d] = f;
+    aa += (double)f * (double)f;
+    amax = fmaxf(amax, fabsf(f));
   }
+  aavec[leaf] = (float)aa;
+  atomicMax(amax_bits, __float_as_int(amax));
+}
+
+__global__ void pack_leaves_kernel(const float* __restrict__ a32, int DP, int Lp,
+                                   const int* __restrict__ amax_bits, f16x8* __restrict__ apack,
+                                   float* __restrict__ scal) {
+  const int S = DP / 32;
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int ka = scale_exponent_bits(*amax_bits);
+  if (u == 0) scal[0] = pow2f(-ka);
+  if (u >= (int64_t)(Lp / kLT) * S * 2 * 64) return;
+  const int lane = (int)(u & 63);
+  const int part = (int)((u >> 6) & 1);
+  const int64_t ts = u >> 7;
+  const int s = (int)(ts % S);
+  const int T = (int)(ts / S);
+  const int leaf = kLT * T + (lane & 15);
+  const int kg = lane >> 4;
+  const float sa = pow2f(ka);
+  f16x8 out;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int dim = 32 * s + 16 * (e >> 2) + 4 * kg + (e & 3);
+    const float v = a32[(int64_t)leaf * DP + dim] * sa;
+    const _Float16 h = (_Float16)v;
+    out[e] = part == 0 ? h : (_Float16)(v - (float)h);
+  }
+  apack[u] = out;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -184,8 +206,6 @@ int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {
   return BNPVI_OK;
 }
 
-template <> int estep_dispatch<8>(const EstepArgs&);
-template <> int estep_dispatch<16>(const EstepArgs&);
 template <> int estep_dispatch<32>(const EstepArgs&);
 template <> int estep_dispatch<64>(const EstepArgs&);
 template <> int estep_dispatch<128>(const EstepArgs&);
@@ -196,27 +216,35 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
                  double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
                  hipStream_t s) {
   const int DP = bnpvi_padded_dim(D);
-  // the streamed regime reads whole chunks of the packed operands: pad to 4 tiles
-  const int LpPack = round_up(t->Lp, 128);
-  int rc = ctx->pack.ensure(((size_t)LpPack * DP + LpPack) * sizeof(float));
+  // the streamed regime reads whole chunks of the packed operands: pad to a chunk of tiles
+  const int LpPack = round_up(t->Lp, kLT * kStreamNT);
+  // workspace: [apack f16 hi/lo: LpPack*DP*4 B][a32: LpPack*DP*4 B][aa: LpPack*4 B][scal 16 B]
+  const size_t img = (size_t)LpPack * DP * 4;
+  int rc = ctx->pack.ensure(2 * img + (size_t)LpPack * 4 + 16);
   if (rc) return rc;
-  float* apack = (float*)ctx->pack.ptr;
-  float* cvec = apack + (size_t)LpPack * DP;
+  char* base = (char*)ctx->pack.ptr;
+  f16x8* apack = (f16x8*)base;
+  float* a32 = (float*)(base + img);
+  float* aavec = (float*)(base + 2 * img);
+  float* scal = aavec + LpPack;          // [0] = 2^-ka, [1] = bits of max|alpha| (int)
+  int* amax_bits = (int*)(scal + 1);
+  BNPVI_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int), s));
+  hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 64)), dim3(64), 0, s, alpha, D, DP,
+                     t->d_node_of_leaf, t->L, LpPack, a32, aavec, amax_bits);
+  BNPVI_LAUNCH_CHECK();
   {
-    const int64_t work = (int64_t)LpPack * DP;
-    hipLaunchKernelGGL(pack_leaves_kernel, dim3((unsigned)ceil_div(work, 256)), dim3(256), 0, s, alpha,
-                       D, DP, t->d_node_of_leaf, t->L, LpPack, apack, cvec);
+    const int64_t units = (int64_t)(LpPack / kLT) * (DP / 32) * 2 * 64;
+    hipLaunchKernelGGL(pack_leaves_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, s, a32, DP,
+                       LpPack, amax_bits, apack, scal);
     BNPVI_LAUNCH_CHECK();
   }
   if (N == 0) {
     if (estats) BNPVI_HIP(hipMemsetAsync(estats, 0, (size_t)2 * t->L * sizeof(double), s));
     return BNPVI_OK;
   }
-  EstepArgs a{ctx, t, Z, ldz, vid, N, apack, cvec, prior, (float)(0.5 * sZ), mode,
+  EstepArgs a{ctx, t, Z, ldz, vid, N, apack, aavec, a32, scal, prior, (float)(0.5 * sZ), mode,
               phi, logphi, assign, estats, s};
   switch (DP) {
-    case 8: return estep_dispatch<8>(a);
-    case 16: return estep_dispatch<16>(a);
     case 32: return estep_dispatch<32>(a);
     case 64: return estep_dispatch<64>(a);
     case 128: return estep_dispatch<128>(a);

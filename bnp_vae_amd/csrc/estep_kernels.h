@@ -4,29 +4,35 @@
 // replacing /root/reference/src/var_inf.py:313-357 and :383-393 (the per-leaf NumPy norm, the
 // per-frame Python loop with two list.index lookups, and the five tree walks of the softmax).
 //
-// Layout of the dense part.  ||z-a||^2 = ||z||^2 - 2 z.a + ||a||^2; only z.a is matrix-shaped
-// and runs on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains) with
-//     rows  i  = leaves  (A operand = alpha, from LDS or L2, pre-packed in operand order)
-//     cols  j  = frames  (B operand = Z, 32 frames per wave, the row kept in registers)
-// so that the accumulator puts one FRAME per lane and its LEAVES in registers: max / sum-exp
-// of the softmax are in-register loops plus ONE cross-lane exchange (lane <-> lane^32), and a
-// lane owns 4 consecutive leaves per register quad => 16-byte phi stores.  The accumulator is
-// seeded with -||a||^2/2 so d^2 = ||z||^2 - 2*acc.
+// Dense part.  ||z-a||^2 = ||z||^2 - 2 z.a + ||a||^2; only z.a is matrix-shaped.  It runs on
+// the f16 matrix pipe (v_mfma_f32_16x16x32_f16, 16x the f32-MFMA rate) WITHOUT giving up fp32
+// accuracy: every fp32 operand is split exactly into hi + lo halves (11 + 11 significant bits
+// after a power-of-two scaling that keeps both halves in f16 range),
+//     z.a = zh.ah + zl.ah + zh.al      (zl.al ~ 2^-22 relative, dropped)
+// three products per K-step, fp32 accumulation in the matrix core.  Operand rounding is
+// <= 2^-22 relative per element -- below the fp32 accumulation rounding that an all-fp32
+// kernel has as well (measured against the fp64 oracle in tests/test_gpu_parity.py).
 //
-// The contraction index (latent dim) is permuted so that each lane's Z fragment is one
-// float4 of its own row: lane (j, h=lane>>5) holds dims 8q+4h+{0..3} in zreg[q]; alpha is
-// packed by pack_leaves_kernel in exactly that order: apack[((t*(DP/8)+q)*64+lane)*4+c] =
-// alpha[leaf 32t+(lane&31)][dim 8q+4(lane>>5)+c], so one ds_read_b128 / global_load_dwordx4
-// per lane feeds four MFMAs and is conflict-free / coalesced.
+// Layout.  rows i = leaves (A operand = alpha, pre-packed in operand order, from LDS or L2),
+// cols j = frames (B operand = Z, 16 frames per wave tile, converted in registers).  The
+// accumulator then holds one FRAME per lane column and 4 consecutive LEAVES per lane
+// (row = 4*(lane>>4)+reg), so max / sum-exp of the softmax are in-register loops plus two
+// cross-lane exchanges (lane^16, lane^32), and prior loads / phi stores are 16 B per lane,
+// 64 B contiguous per frame.  The contraction index is permuted so that a lane's fragment of
+// K-step s is two float4 of its own row: dims 32s+4kg+{0..3} and 32s+16+4kg+{0..3}
+// (kg = lane>>4); pack_leaves_kernel writes alpha in exactly that order.
 #pragma once
 
 #include "common.h"
 
 namespace bnpvi {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kEWaves = 4;            // waves per workgroup
+constexpr int kFT = 16;               // frames per wave tile
+constexpr int kLT = 16;               // leaves per MFMA tile
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 // d^2 from the expansion carries an absolute error ~ 2e-7*(||z||^2+||a||^2); below this
@@ -34,260 +40,316 @@ constexpr float kLn2 = 0.6931471805599453f;
 // is recomputed by direct differences (rare: a frame that coincides with a leaf mean, which is
 // exactly what weighted_kmeans produces right after a split).
 constexpr float kRefineRel = 6.25e-6f;
+constexpr int kScaleExp = 13;         // operands are scaled so that max |x| lies in [2^13, 2^14)
 
-__device__ __forceinline__ int leaf_slot(int r, int h) { return 8 * (r >> 2) + 4 * h + (r & 3); }
+// power-of-two scale that brings `amax` into [2^13, 2^14); returns the exponent k (scale = 2^k)
+__host__ __device__ __forceinline__ int scale_exponent_bits(int float_bits) {
+  int eb = (float_bits >> 23) & 0xff;
+  eb = eb < 80 ? 80 : eb;                      // |x| < 2^-47 is treated as 2^-47 (k <= 60)
+  return kScaleExp - (eb - 127);
+}
+__device__ __forceinline__ float pow2f(int k) { return __int_as_float((127 + k) << 23); }
 
-// index of alpha[leaf][dim] inside the packed operand image (floats)
-template <int DP>
-__device__ __forceinline__ int pack_index(int leaf, int dim) {
-  return (((leaf >> 5) * (DP / 8) + (dim >> 3)) * 64 + ((dim >> 2) & 1) * 32 + (leaf & 31)) * 4 + (dim & 3);
+// exact hi/lo split of 8 scaled fp32 values into two f16x8 fragments
+__device__ __forceinline__ void split8(const float4& a, const float4& b, float s, f16x8& hi, f16x8& lo) {
+  const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)v[e];
+    hi[e] = h;
+    lo[e] = (_Float16)(v[e] - (float)h);
+  }
 }
 
+// Everything a wave needs to know about the leaf side
+struct LeafOperands {
+  const f16x8* a;        // packed alpha: [(T*S+s)*2+part][64 lanes] x 8 halfs (LDS or global)
+  const float* aa;       // ||alpha_l||^2 (fp32 of the fp32-rounded alpha), tile-relative
+  const float* a32;      // row-major fp32 alpha [leaf][DP], tile-relative (refinement path)
+  float inv_sa;          // 2^-ka, ka = scale exponent of alpha
+};
+
 // ------------------------------------------------------------------------------------------
-// Cross term + squared distance for NT leaf tiles of one 32-frame tile.  On return acc[t][r]
-// holds ||z - alpha||^2 of frame (lane&31) to leaf 32t+slot(r,h) (tile-relative numbering).
-//   a4 / cv : packed alpha / -|alpha|^2/2 of the first tile (LDS in the fused regime, global
-//             in the streamed one);  apack_f : the same image as plain floats (refinement).
+// One wave tile: 16 frames x NT 16-leaf tiles.  zA/zB hold the lane's raw fp32 fragments.
+// On return acc[T][r] = ||z - alpha||^2 for frame (lane&15), leaf 16T + 4(lane>>4) + r.
 // ------------------------------------------------------------------------------------------
 template <int DP, int NT>
 __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int ldz, int64_t row0,
-                                               int64_t N, const float4* a4, const float* cv,
-                                               const float* apack_f, int lane, int lvalid,
-                                               f32x16 (&acc)[NT]) {
-  const int j = lane & 31, h = lane >> 5;
-  int64_t n = row0 + j;
-  if (n >= N) n = N - 1;
-  const float* zrow = Z + n * ldz;
-  float4 zreg[DP / 8];
-  float zz = 0.f;
+                                               int64_t N, const float4 (&zA)[DP / 32],
+                                               const float4 (&zB)[DP / 32], const LeafOperands& lo_,
+                                               int lane, int tiles_valid, int lvalid,
+                                               f32x4 (&acc)[NT]) {
+  constexpr int S = DP / 32;
+  const int kg = lane >> 4;
+  float zz = 0.f, amax = 0.f;
 #pragma unroll
-  for (int q = 0; q < DP / 8; ++q) {
-#ifdef BNPVI_ABLATE_NOZLOAD
-    zreg[q] = make_float4(0.01f * lane, 0.02f * q, 0.5f, -0.25f);
-    (void)zrow;
-#else
-    zreg[q] = *reinterpret_cast<const float4*>(zrow + 8 * q + 4 * h);
-#endif
-    zz = fmaf(zreg[q].x, zreg[q].x, zz);
-    zz = fmaf(zreg[q].y, zreg[q].y, zz);
-    zz = fmaf(zreg[q].z, zreg[q].z, zz);
-    zz = fmaf(zreg[q].w, zreg[q].w, zz);
-  }
-  zz += __shfl_xor(zz, 32);
-
+  for (int s = 0; s < S; ++s) {
+    const float v[8] = {zA[s].x, zA[s].y, zA[s].z, zA[s].w, zB[s].x, zB[s].y, zB[s].z, zB[s].w};
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 c4 = *reinterpret_cast<const float4*>(cv + 32 * t + 8 * g + 4 * h);
-      acc[t][4 * g + 0] = c4.x;
-      acc[t][4 * g + 1] = c4.y;
-      acc[t][4 * g + 2] = c4.z;
-      acc[t][4 * g + 3] = c4.w;
+    for (int e = 0; e < 8; ++e) {
+      zz = fmaf(v[e], v[e], zz);
+      amax = fmaxf(amax, fabsf(v[e]));
     }
   }
+  zz += __shfl_xor(zz, 16);
+  zz += __shfl_xor(zz, 32);
+  amax = fmaxf(amax, __shfl_xor(amax, 16));
+  amax = fmaxf(amax, __shfl_xor(amax, 32));
+  const int kz = scale_exponent_bits(__float_as_int(amax));
+  const float sz = pow2f(kz);
+  f16x8 bh[S], bl[S];
 #pragma unroll
-  for (int q = 0; q < DP / 8; ++q) {
+  for (int s = 0; s < S; ++s) split8(zA[s], zB[s], sz, bh[s], bl[s]);
+
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+  for (int T = 0; T < NT; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      if (T < tiles_valid) {
 #ifdef BNPVI_ABLATE_NOMFMA
-      acc[t][q & 15] += zreg[q].x + zreg[q].y + zreg[q].z + zreg[q].w;
+        acc[T][s & 3] += (float)bh[s][0] + (float)bl[s][1];
 #else
-      const float4 a = a4[(t * (DP / 8) + q) * 64 + lane];
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zreg[q].x, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zreg[q].y, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zreg[q].z, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zreg[q].w, acc[t], 0, 0, 0);
+        const f16x8 ah = lo_.a[((T * S + s) * 2 + 0) * 64 + lane];
+        const f16x8 al = lo_.a[((T * S + s) * 2 + 1) * 64 + lane];
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], acc[T], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[s], acc[T], 0, 0, 0);
+        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], acc[T], 0, 0, 0);
 #endif
+      }
     }
   }
   // d^2 in place; remember which entries are too cancelled to trust
-  unsigned long long pend = 0ull;
+  const float unscale = -2.f * pow2f(-kz) * lo_.inv_sa;
+  unsigned pend = 0u;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  for (int T = 0; T < NT; ++T) {
+    const float4 aa4 = *reinterpret_cast<const float4*>(lo_.aa + kLT * T + 4 * kg);
+    const float aav[4] = {aa4.x, aa4.y, aa4.z, aa4.w};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int slot = 32 * t + leaf_slot(r, h);
-      const float aa = -2.f * cv[slot];
-      const float v = fmaxf(fmaf(-2.f, acc[t][r], zz), 0.f);
-      const float sn = zz + aa;
-      if ((v < kRefineRel * sn * sn) && (slot < lvalid)) pend |= 1ull << (t * 16 + r);
-      acc[t][r] = v;
+    for (int r = 0; r < 4; ++r) {
+      const float sn = zz + aav[r];
+      const float v = fmaxf(fmaf(unscale, acc[T][r], sn), 0.f);
+      if ((v < kRefineRel * sn * sn) && (kLT * T + 4 * kg + r < lvalid)) pend |= 1u << ((T * 4 + r) & 31);
+      acc[T][r] = v;
     }
   }
   // rare path, one flagged (frame, leaf) pair at a time: the whole wave computes that pair's
-  // distance by direct differences (64 lanes split the dims), the owning lane patches it in.
+  // distance by direct fp32 differences (64 lanes split the dims), the owning lane patches it.
+  // (NT > 8: the 32-bit mask aliases tiles T and T+8; every aliased slot is then patched with
+  //  its own exact value, which is harmless.)
   while (true) {
-    const unsigned long long b = __ballot(pend != 0ull);
+    const unsigned long long b = __ballot(pend != 0u);
     if (b == 0ull) break;
     const int src = __ffsll((long long)b) - 1;
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)(pend & 0xffffffffull), src);
-    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(pend >> 32), src);
-    const unsigned long long pm = ((unsigned long long)hi << 32) | lo;
-    const int idx = __ffsll((long long)pm) - 1;
-    const int leaf = 32 * (idx >> 4) + leaf_slot(idx & 15, src >> 5);
-    int64_t ns = row0 + (src & 31);
+    const unsigned pm = __builtin_amdgcn_readlane(pend, src);
+    const int idx = __ffs((int)pm) - 1;
+    int64_t ns = row0 + (src & 15);
     if (ns >= N) ns = N - 1;
-    float p = 0.f;
-    for (int d = lane; d < DP; d += 64) {
-      const float df = Z[ns * ldz + d] - apack_f[pack_index<DP>(leaf, d)];
-      p = fmaf(df, df, p);
+#pragma unroll
+    for (int Tb = 0; Tb < NT; Tb += 8) {
+      const int Tq = Tb + (idx >> 2);
+      if (Tq < tiles_valid) {
+        const int leaf = kLT * Tq + 4 * (src >> 4) + (idx & 3);
+        float p = 0.f;
+        for (int d = lane; d < DP; d += 64) {
+          const float df = Z[ns * ldz + d] - lo_.a32[leaf * DP + d];
+          p = fmaf(df, df, p);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off);
+        if (lane == src) {
+#pragma unroll
+          for (int T = Tb; T < (Tb + 8 < NT ? Tb + 8 : NT); ++T)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (idx == (T - Tb) * 4 + r) acc[T][r] = p;
+        }
+      }
     }
+    if (lane == src) pend &= ~(1u << idx);
+  }
+}
+
+template <int DP>
+__device__ __forceinline__ void load_ztile(const float* __restrict__ Z, int ldz, int64_t row0, int64_t N,
+                                           int lane, float4 (&zA)[DP / 32], float4 (&zB)[DP / 32]) {
+  int64_t n = row0 + (lane & 15);
+  if (n >= N) n = N - 1;
+  const float* zrow = Z + n * ldz + 4 * (lane >> 4);
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off);
-    if (lane == src) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (idx == t * 16 + r) acc[t][r] = p;
-      pend &= ~(1ull << idx);
-    }
+  for (int s = 0; s < DP / 32; ++s) {
+#ifdef BNPVI_ABLATE_NOZLOAD
+    zA[s] = make_float4(0.01f * lane, 0.02f * s, 0.5f, -0.25f);
+    zB[s] = make_float4(0.03f * lane, 0.01f * s, 0.25f, -0.5f);
+    (void)zrow;
+#else
+    zA[s] = *reinterpret_cast<const float4*>(zrow + 32 * s);
+    zB[s] = *reinterpret_cast<const float4*>(zrow + 32 * s + 16);
+#endif
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused regime: Lp = 32*NT <= 128 -- the whole row of logits stays in registers, phi is
-// written once (algorithmic traffic: read Z once, write phi once).
+// Fused regime: the whole row of logits of a frame stays in registers (4*NT per lane), phi is
+// written once (algorithmic traffic: read Z once, write phi once).  NT = 16-leaf tiles.
 // ------------------------------------------------------------------------------------------
-template <int DP, int NT, bool STATS>
-__global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2 && !STATS) ? 2 : 1) void estep_fused_kernel(
-    const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L,
-    const float* __restrict__ apack, const float* __restrict__ cvec,
-    const float* __restrict__ prior, float half_sz, float* __restrict__ phi,
-    float* __restrict__ logphi, int32_t* __restrict__ assign, double* __restrict__ eslab) {
-  constexpr int Lp = 32 * NT;
+template <int DP, int NT, bool HARD, bool STATS>
+__global__ __launch_bounds__(kEWaves * 64) void estep_fused_kernel(
+    const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
+    const f16x8* __restrict__ apack, const float* __restrict__ aavec, const float* __restrict__ a32,
+    const float* __restrict__ scal /* [0] = 2^-ka */, const float* __restrict__ prior, float half_sz,
+    float* __restrict__ phi, float* __restrict__ logphi, int32_t* __restrict__ assign,
+    double* __restrict__ eslab) {
+  constexpr int S = DP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float4* a_lds = reinterpret_cast<float4*>(smem_raw);                  // [NT*(DP/8)*64]
-  float* c_lds = reinterpret_cast<float*>(a_lds + NT * (DP / 8) * 64);  // [Lp]
-  double* st_lds = reinterpret_cast<double*>(c_lds + Lp);               // [Lp][2]
+  f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                  // [NT*S*2*64]
+  float* aa_lds = reinterpret_cast<float*>(a_lds + NT * S * 2 * 64);  // [16*NT]
+  double* st_lds = reinterpret_cast<double*>(aa_lds + kLT * NT);      // [16*NT][2]
+  const int tiles_valid = Lp / kLT;
 
-  for (int e = threadIdx.x; e < NT * (DP / 8) * 64; e += blockDim.x)
-    a_lds[e] = reinterpret_cast<const float4*>(apack)[e];
-  for (int e = threadIdx.x; e < Lp; e += blockDim.x) c_lds[e] = cvec[e];
-  for (int e = threadIdx.x; e < 2 * Lp; e += blockDim.x) st_lds[e] = 0.0;
+  for (int e = threadIdx.x; e < tiles_valid * S * 2 * 64; e += blockDim.x) a_lds[e] = apack[e];
+  for (int e = threadIdx.x; e < kLT * NT; e += blockDim.x) aa_lds[e] = e < Lp ? aavec[e] : 0.f;
+  if (STATS)
+    for (int e = threadIdx.x; e < 2 * kLT * NT; e += blockDim.x) st_lds[e] = 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int j = lane & 31;
-  const int h = lane >> 5;
-  const int64_t ntiles = (N + 31) / 32;
-  // per-lane fp32 accumulators of (phi, phi*d^2) per logit register (STATS only; LDS float
-  // atomics were tried instead and stalled the LDS pipe 4x: profiles/r01_notes.md)
-  float s0[STATS ? NT : 1][16], s2[STATS ? NT : 1][16];
+  const int j = lane & 15;
+  const int kg = lane >> 4;
+  const int64_t ntiles = (N + kFT - 1) / kFT;
+  const int64_t stride = (int64_t)gridDim.x * kEWaves;
+  LeafOperands lo_{a_lds, aa_lds, a32, scal[0]};
+
+  float s0[STATS ? NT : 1][4], s2[STATS ? NT : 1][4];
   if (STATS) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int T = 0; T < NT; ++T)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s0[t][r] = s2[t][r] = 0.f;
+      for (int r = 0; r < 4; ++r) s0[T][r] = s2[T][r] = 0.f;
   }
 
-  for (int64_t tile = (int64_t)blockIdx.x * kEWaves + wave; tile < ntiles;
-       tile += (int64_t)gridDim.x * kEWaves) {
-    const int64_t n = tile * 32 + j;
+  int64_t tile = (int64_t)blockIdx.x * kEWaves + wave;
+  float4 zA[S], zB[S];
+  if (tile < ntiles) load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
+
+  for (; tile < ntiles; tile += stride) {
+    const int64_t n = tile * kFT + j;
     const bool ok = n < N;
     const int64_t nn = ok ? n : N - 1;
+#ifdef BNPVI_ABLATE_NOPRIOR
+    const float* prow = nullptr;
+#else
+    const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp;
+#endif
 
-    f32x16 d2[NT];
-    tile_distances<DP, NT>(Z, ldz, tile * 32, N, a_lds, c_lds, reinterpret_cast<const float*>(a_lds),
-                           lane, L, d2);
+    f32x4 d2[NT];
+    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, lo_, lane, tiles_valid, L, d2);
+    // software prefetch of the next tile's rows: in flight during this tile's epilogue
+    if (tile + stride < ntiles) load_ztile<DP>(Z, ldz, (tile + stride) * kFT, N, lane, zA, zB);
 
-    // logits (in place of the prior), running max and arg-max (first index wins ties)
-    const float* prow = prior + (int64_t)vid[nn] * Lp;
-    float lg[NT][16];
+    // logits, running max and arg-max (first index wins ties)
+    f32x4 lg[NT];
     float m = -INFINITY;
     int best = 0x7fffffff;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int T = 0; T < NT; ++T) {
+      float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool tv = T < tiles_valid;
+      if (!HARD && tv && prow) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+      const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#ifdef BNPVI_ABLATE_NOPRIOR
-        const float4 p4 = make_float4(0.f, 0.1f, 0.2f, 0.3f);
-        (void)prow;
-#else
-        const float4 p4 = *reinterpret_cast<const float4*>(prow + 32 * t + 8 * g + 4 * h);
-#endif
-        const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int r = 4 * g + c;
-          const float v = fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[t][r]), pr[c]);
-          lg[t][r] = v;
-          if (v > m) {
-            m = v;
-            best = 32 * t + leaf_slot(r, h);
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int leaf = kLT * T + 4 * kg + r;
+        float v;
+        if (HARD)
+          v = leaf < L ? -d2[T][r] : -INFINITY;
+        else
+          v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
+        lg[T][r] = v;
+        if (v > m) {
+          m = v;
+          best = leaf;
         }
       }
-    {
-      const float om = __shfl_xor(m, 32);
-      const int ob = __shfl_xor(best, 32);
+    }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      const float om = __shfl_xor(m, off);
+      const int ob = __shfl_xor(best, off);
       if (om > m || (om == m && ob < best)) {
         m = om;
         best = ob;
       }
     }
-    float ssum = 0.f;
+    float lse = 0.f;
+    if (!HARD) {
+      float ssum = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int T = 0; T < NT; ++T)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float x = lg[t][r] - m;
-        lg[t][r] = x;
-        ssum += __builtin_amdgcn_exp2f(x * kLog2e);
-      }
-    ssum += __shfl_xor(ssum, 32);
-    const float lse = __builtin_amdgcn_logf(ssum) * kLn2;
+        for (int r = 0; r < 4; ++r) {
+          const float x = lg[T][r] - m;
+          lg[T][r] = x;
+          ssum += __builtin_amdgcn_exp2f(x * kLog2e);
+        }
+      ssum += __shfl_xor(ssum, 16);
+      ssum += __shfl_xor(ssum, 32);
+      lse = __builtin_amdgcn_logf(ssum) * kLn2;
+    }
 
     float* prow_out = phi + n * Lp;
     float* lrow_out = logphi ? logphi + n * Lp : nullptr;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
+    for (int T = 0; T < NT; ++T) {
+      if (T < tiles_valid) {
         float pv[4], lv[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int r = 4 * g + c;
-          lv[c] = lg[t][r] - lse;
-          pv[c] = __builtin_amdgcn_exp2f(lv[c] * kLog2e);
+        for (int r = 0; r < 4; ++r) {
+          if (HARD) {
+            const bool hit = (kLT * T + 4 * kg + r) == best;
+            pv[r] = hit ? 1.f : 0.f;
+            lv[r] = hit ? 0.f : -INFINITY;
+          } else {
+            lv[r] = lg[T][r] - lse;
+            pv[r] = __builtin_amdgcn_exp2f(lv[r] * kLog2e);
+          }
           if (STATS && ok) {
-            s0[t][r] += pv[c];
-            s2[t][r] = fmaf(pv[c], d2[t][r], s2[t][r]);
+            s0[T][r] += pv[r];
+            s2[T][r] = fmaf(pv[r], d2[T][r], s2[T][r]);
           }
         }
 #ifdef BNPVI_ABLATE_NOSTORE
-        if (ok && pv[0] + pv[1] + pv[2] + pv[3] == -123.f) {
+        if (ok && pv[0] + pv[1] == -123.f) {
 #else
         if (ok) {
 #endif
-          *reinterpret_cast<float4*>(prow_out + 32 * t + 8 * g + 4 * h) =
-              make_float4(pv[0], pv[1], pv[2], pv[3]);
+          *reinterpret_cast<float4*>(prow_out + kLT * T + 4 * kg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
           if (lrow_out)
-            *reinterpret_cast<float4*>(lrow_out + 32 * t + 8 * g + 4 * h) =
-                make_float4(lv[0], lv[1], lv[2], lv[3]);
+            *reinterpret_cast<float4*>(lrow_out + kLT * T + 4 * kg) = make_float4(lv[0], lv[1], lv[2], lv[3]);
         }
       }
     }
-    if (assign && ok && h == 0) assign[n] = best;
+    if (assign && ok && kg == 0) assign[n] = best;
   }
 
   if (STATS) {
-    // reduce the per-lane leaf accumulators over the 32 frame lanes of each half-wave, then
+    // reduce the per-lane leaf accumulators over the 16 frame lanes of each lane group, then
     // fp64 accumulation in LDS, one slab per workgroup (summed in fixed order afterwards)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
+    for (int T = 0; T < NT; ++T) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float a = s0[t][r], b = s2[t][r];
+      for (int r = 0; r < 4; ++r) {
+        float a = s0[T][r], b = s2[T][r];
 #pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
+        for (int off = 1; off < 16; off <<= 1) {
           a += __shfl_xor(a, off);
           b += __shfl_xor(b, off);
         }
         if (j == 0) {
-          const int leaf = 32 * t + leaf_slot(r, h);
+          const int leaf = kLT * T + 4 * kg + r;
           atomicAdd(&st_lds[2 * leaf], (double)a);
           atomicAdd(&st_lds[2 * leaf + 1], (double)b);
         }
@@ -300,65 +362,66 @@ __global__ __launch_bounds__(kEWaves * 64, (DP <= 64 && NT <= 2 && !STATS) ? 2 :
 }
 
 // ------------------------------------------------------------------------------------------
-// Streamed regime (larger trees, and the one-hot mode), pass A: raw logits for one 32-frame
-// tile x one chunk of NT leaf tiles, written into phi; part[n][chunk] = (max, sum exp(logit-max))
-// in soft mode, (max of -d^2, arg-max leaf as float bits) in hard mode.
+// Streamed regime (trees too large for the fused kernel), pass A: raw logits for one 16-frame
+// tile x one chunk of NT 16-leaf tiles, written into phi; part[n][chunk] = (max,
+// sum exp(logit-max)) in soft mode, (max of -d^2, arg-max leaf as float bits) in hard mode.
+// Operands come straight from L2 (the packed image is lane-linear: 1 KiB per wave-load).
 // ------------------------------------------------------------------------------------------
 template <int DP, int NT, bool HARD>
 __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
-    const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L,
-    int Lp, const float* __restrict__ apack, const float* __restrict__ cvec,
-    const float* __restrict__ prior, float half_sz, float* __restrict__ phi,
-    float2* __restrict__ part, int nchunk) {
+    const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
+    const f16x8* __restrict__ apack, const float* __restrict__ aavec, const float* __restrict__ a32,
+    const float* __restrict__ scal, const float* __restrict__ prior, float half_sz,
+    float* __restrict__ phi, float2* __restrict__ part, int nchunk) {
+  constexpr int S = DP / 32;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int j = lane & 31;
-  const int h = lane >> 5;
+  const int j = lane & 15;
+  const int kg = lane >> 4;
   const int chunk = blockIdx.y;
-  const int t0 = chunk * NT;                   // first leaf tile of this chunk
-  const int64_t ntiles = (N + 31) / 32;
-  const float* ap = apack + (int64_t)t0 * (DP / 8) * 256;
-  const float4* a4 = reinterpret_cast<const float4*>(ap);
-  const float* cv = cvec + 32 * t0;
+  const int T0 = chunk * NT;                      // first 16-leaf tile of this chunk
+  int tiles_valid = Lp / kLT - T0;
+  tiles_valid = tiles_valid > NT ? NT : tiles_valid;
+  const int64_t ntiles = (N + kFT - 1) / kFT;
+  LeafOperands lo_{apack + (int64_t)T0 * S * 2 * 64, aavec + kLT * T0, a32 + (int64_t)kLT * T0 * DP, scal[0]};
 
   for (int64_t tile = (int64_t)blockIdx.x * kEWaves + wave; tile < ntiles;
        tile += (int64_t)gridDim.x * kEWaves) {
-    const int64_t n = tile * 32 + j;
+    const int64_t n = tile * kFT + j;
     const bool ok = n < N;
     const int64_t nn = ok ? n : N - 1;
-    f32x16 d2[NT];
-    tile_distances<DP, NT>(Z, ldz, tile * 32, N, a4, cv, ap, lane, L - 32 * t0, d2);
-    const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp + 32 * t0;
+    float4 zA[S], zB[S];
+    load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
+    f32x4 d2[NT];
+    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, lo_, lane, tiles_valid, L - kLT * T0, d2);
+    const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp + kLT * T0;
     float m = -INFINITY;
     int best = 0x7fffffff;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bool tile_ok = 32 * (t0 + t) < Lp;
+    for (int T = 0; T < NT; ++T) {
+      const bool tv = T < tiles_valid;
+      float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!HARD && tv) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+      const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!HARD && tile_ok) p4 = *reinterpret_cast<const float4*>(prow + 32 * t + 8 * g + 4 * h);
-        const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int r = 4 * g + c;
-          const int leaf = 32 * (t0 + t) + leaf_slot(r, h);
-          float v;
-          if (HARD)
-            v = leaf < L ? -d2[t][r] : -INFINITY;
-          else
-            v = tile_ok ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[t][r]), pr[c]) : -INFINITY;
-          d2[t][r] = v;
-          if (v > m) {
-            m = v;
-            best = leaf;
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int leaf = kLT * (T0 + T) + 4 * kg + r;
+        float v;
+        if (HARD)
+          v = leaf < L ? -d2[T][r] : -INFINITY;
+        else
+          v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
+        d2[T][r] = v;
+        if (v > m) {
+          m = v;
+          best = leaf;
         }
       }
     }
-    {
-      const float om = __shfl_xor(m, 32);
-      const int ob = __shfl_xor(best, 32);
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+      const float om = __shfl_xor(m, off);
+      const int ob = __shfl_xor(best, off);
       if (om > m || (om == m && ob < best)) {
         m = om;
         best = ob;
@@ -370,24 +433,21 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
     } else {
       float ssum = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int T = 0; T < NT; ++T)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ssum += (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((d2[t][r] - m) * kLog2e);
+        for (int r = 0; r < 4; ++r)
+          ssum += (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((d2[T][r] - m) * kLog2e);
+      ssum += __shfl_xor(ssum, 16);
       ssum += __shfl_xor(ssum, 32);
       second = ssum;
     }
     if (ok) {
-      float* row = phi + n * Lp + 32 * t0;
+      float* row = phi + n * Lp + kLT * T0;
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (32 * (t0 + t) < Lp) {
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(row + 32 * t + 8 * g + 4 * h) =
-                make_float4(d2[t][4 * g], d2[t][4 * g + 1], d2[t][4 * g + 2], d2[t][4 * g + 3]);
-        }
-      if (h == 0) part[n * nchunk + chunk] = make_float2(m, second);
+      for (int T = 0; T < NT; ++T)
+        if (T < tiles_valid)
+          *reinterpret_cast<float4*>(row + kLT * T + 4 * kg) = make_float4(d2[T][0], d2[T][1], d2[T][2], d2[T][3]);
+      if (kg == 0) part[n * nchunk + chunk] = make_float2(m, second);
     }
   }
 }
@@ -400,8 +460,10 @@ struct EstepArgs {
   int ldz;
   const int32_t* vid;
   int64_t N;
-  const float* apack;
-  const float* cvec;
+  const f16x8* apack;
+  const float* aavec;
+  const float* a32;
+  const float* scal;
   const float* prior;
   float half_sz;
   int mode;
@@ -417,6 +479,6 @@ template <int DP> int estep_dispatch(const EstepArgs& a);
 // shared (estep.hip)
 int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk);
 int estep_reduce_slabs(const EstepArgs& a, const double* eslab, int nslab);
-constexpr int kStreamNT = 2;      // leaf tiles per chunk in the streamed regime (64 leaves)
+constexpr int kStreamNT = 8;      // 16-leaf tiles per chunk in the streamed regime (128 leaves)
 
 }  // namespace bnpvi

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_padding_rules():
     from bnp_vae_amd import _lib
     assert [_lib.lib.bnpvi_padded_dim(d) for d in (1, 8, 9, 32, 33, 64, 200, 256, 257)] == \
-        [8, 8, 16, 32, 64, 64, 256, 256, -1]
+        [32, 32, 32, 32, 64, 64, 256, 256, -1]
     assert [_lib.lib.bnpvi_padded_leaves(l) for l in (1, 25, 32, 33, 64, 512, 7776)] == \
         [32, 32, 32, 64, 64, 512, 7776]
 
