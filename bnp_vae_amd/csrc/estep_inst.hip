@@ -13,24 +13,45 @@ static size_t fused_lds_bytes() {
   return (size_t)NT * (DP / 32) * 2 * 64 * 16 + (size_t)kLT * NT * 4 + (size_t)kLT * NT * 16;
 }
 
+// workgroups of kEWaves waves that fit a CU at once: one wave per SIMD each, so the count is
+// the waves/SIMD the register allocation allows (512 registers per lane per SIMD, granule 8),
+// capped by the LDS and by 8 (MI355X_MICROARCH.md, register files)
+static int resident_blocks(const void* kern, size_t lds, int* out) {
+  hipFuncAttributes fa;
+  BNPVI_HIP(hipFuncGetAttributes(&fa, kern));
+  int regs = fa.numRegs > 0 ? fa.numRegs : 128;
+  regs = (regs + 7) / 8 * 8;
+  int b = 512 / regs;
+  if (b > 8) b = 8;
+  if (b < 1) b = 1;
+  const size_t per = lds + (size_t)fa.sharedSizeBytes;
+  if (per > 0) {
+    const int bl = (int)((size_t)kMaxLdsBytes / per);
+    if (bl < b) b = bl;
+  }
+  *out = b < 1 ? 1 : b;
+  return BNPVI_OK;
+}
+
 template <int DP, int NT, bool HARD, bool STATS>
 static int launch_fused(const EstepArgs& a) {
+  // two Z tiles in flight per wave where a tile is cheap to hold (16 registers at DP = 64)
+  constexpr int PF = (DP <= 64 && NT <= 8) ? 2 : 1;
   const int L = a.tree->L, Lp = a.tree->Lp;
   const size_t lds = fused_lds_bytes<DP, NT>();
-  auto k = estep_fused_kernel<DP, NT, HARD, STATS>;
+  auto k = estep_fused_kernel<DP, NT, PF, HARD, STATS>;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  int per_cu = 0;
-  BNPVI_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k, kEWaves * 64, lds));
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu > 8) per_cu = 8;
+  int per_cu = 1;
+  int rc = resident_blocks((const void*)k, lds, &per_cu);
+  if (rc) return rc;
   const int64_t ntiles = ceil_div(a.N, kFT);
   int64_t blocks = ceil_div(ntiles, kEWaves);
   const int64_t cap = (int64_t)a.ctx->num_cu * per_cu;
   if (blocks > cap) blocks = cap;
   double* eslab = nullptr;
   if (STATS) {
-    int rc = a.ctx->slabs.ensure((size_t)blocks * 2 * L * sizeof(double));
+    rc = a.ctx->slabs.ensure((size_t)blocks * 2 * L * sizeof(double));
     if (rc) return rc;
     eslab = (double*)a.ctx->slabs.ptr;
   }

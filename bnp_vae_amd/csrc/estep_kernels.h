@@ -73,10 +73,17 @@ struct LeafOperands {
 // One wave tile: 16 frames x NT 16-leaf tiles.  zA/zB hold the lane's raw fp32 fragments.
 // On return acc[T][r] = ||z - alpha||^2 for frame (lane&15), leaf 16T + 4(lane>>4) + r.
 // ------------------------------------------------------------------------------------------
+template <int DP>
+__device__ __forceinline__ void load_ztile(const float* __restrict__ Z, int ldz, int64_t row0, int64_t N,
+                                           int lane, float4 (&zA)[DP / 32], float4 (&zB)[DP / 32]);
+
+// next_row0 >= 0: once zA/zB are converted they are reloaded with the rows of that later tile
+// (software prefetch: the loads are in flight during this tile's MFMAs and epilogue).
 template <int DP, int NT>
 __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int ldz, int64_t row0,
-                                               int64_t N, const float4 (&zA)[DP / 32],
-                                               const float4 (&zB)[DP / 32], const LeafOperands& lo_,
+                                               int64_t N, float4 (&zA)[DP / 32],
+                                               float4 (&zB)[DP / 32], int64_t next_row0,
+                                               const LeafOperands& lo_,
                                                int lane, int tiles_valid, int lvalid,
                                                f32x4 (&acc)[NT]) {
   constexpr int S = DP / 32;
@@ -100,6 +107,9 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   f16x8 bh[S], bl[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) split8(zA[s], zB[s], sz, bh[s], bl[s]);
+#ifndef BNPVI_LATE_PREFETCH
+  if (next_row0 >= 0) load_ztile<DP>(Z, ldz, next_row0, N, lane, zA, zB);
+#endif
 
 #pragma unroll
   for (int T = 0; T < NT; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -194,14 +204,156 @@ __device__ __forceinline__ void load_ztile(const float* __restrict__ Z, int ldz,
 // ------------------------------------------------------------------------------------------
 // Fused regime: the whole row of logits of a frame stays in registers (4*NT per lane), phi is
 // written once (algorithmic traffic: read Z once, write phi once).  NT = 16-leaf tiles.
+// A wave keeps PF tiles of Z in flight (PF register sets, each reloaded right after its
+// conversion to f16 fragments).
 // ------------------------------------------------------------------------------------------
+struct FusedParams {
+  const float* Z;
+  int ldz;
+  const int32_t* vid;
+  int64_t N;
+  int L, Lp;
+  const float* prior;
+  float half_sz;
+  float* phi;
+  float* logphi;
+  int32_t* assign;
+};
+
 template <int DP, int NT, bool HARD, bool STATS>
+__device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOperands& lo_, int64_t tile,
+                                           int64_t next_tile, int64_t ntiles, int lane, int tiles_valid,
+                                           float4 (&zA)[DP / 32], float4 (&zB)[DP / 32],
+                                           float (&s0)[STATS ? NT : 1][4], float (&s2)[STATS ? NT : 1][4]) {
+  const int j = lane & 15;
+  const int kg = lane >> 4;
+  const int64_t n = tile * kFT + j;
+  const bool ok = n < p.N;
+  const int64_t nn = ok ? n : p.N - 1;
+#ifdef BNPVI_ABLATE_NOPRIOR
+  const float* prow = nullptr;
+#else
+  const float* prow = HARD ? nullptr : p.prior + (int64_t)p.vid[nn] * p.Lp;
+#endif
+
+  f32x4 d2[NT];
+  tile_distances<DP, NT>(p.Z, p.ldz, tile * kFT, p.N, zA, zB, next_tile < ntiles ? next_tile * kFT : -1,
+                         lo_, lane, tiles_valid, p.L, d2);
+
+  // logits, running max and arg-max (first index wins ties)
+  f32x4 lg[NT];
+  float m = -INFINITY;
+  int best = 0x7fffffff;
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool tv = T < tiles_valid;
+    if (!HARD && tv && prow) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+    const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int leaf = kLT * T + 4 * kg + r;
+      float v;
+      if (HARD)
+        v = leaf < p.L ? -d2[T][r] : -INFINITY;
+      else
+        v = tv ? fmaf(-p.half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
+      lg[T][r] = v;
+      if (v > m) {
+        m = v;
+        best = leaf;
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 16; off < 64; off <<= 1) {
+    const float om = __shfl_xor(m, off);
+    const int ob = __shfl_xor(best, off);
+    if (om > m || (om == m && ob < best)) {
+      m = om;
+      best = ob;
+    }
+  }
+  // soft mode: e = exp(logit - max) once per entry and phi = e / sum; when log phi is asked
+  // for, the slot keeps logit - max instead and phi = exp(log phi) (a second exponential)
+#ifdef BNPVI_TEST_NOLOG
+  const bool want_log = false;
+#else
+  const bool want_log = p.logphi != nullptr;
+#endif
+  float lse = 0.f, inv = 0.f;
+  if (!HARD) {
+    float ssum = 0.f;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float x = lg[T][r] - m;
+        const float e = __builtin_amdgcn_exp2f(x * kLog2e);
+        ssum += e;
+        lg[T][r] = want_log ? x : e;
+      }
+    ssum += __shfl_xor(ssum, 16);
+    ssum += __shfl_xor(ssum, 32);
+    lse = __builtin_amdgcn_logf(ssum) * kLn2;
+    inv = __builtin_amdgcn_rcpf(ssum);
+  }
+
+  float* prow_out = p.phi + n * p.Lp;
+  float* lrow_out = want_log ? p.logphi + n * p.Lp : nullptr;
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    if (T < tiles_valid) {
+      float pv[4], lv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (HARD) {
+          const bool hit = (kLT * T + 4 * kg + r) == best;
+          pv[r] = hit ? 1.f : 0.f;
+          lv[r] = hit ? 0.f : -INFINITY;
+        } else if (want_log) {
+          lv[r] = lg[T][r] - lse;
+          pv[r] = __builtin_amdgcn_exp2f(lv[r] * kLog2e);
+        } else {
+          lv[r] = 0.f;
+          pv[r] = lg[T][r] * inv;
+        }
+        if (STATS && ok) {
+          s0[T][r] += pv[r];
+          s2[T][r] = fmaf(pv[r], d2[T][r], s2[T][r]);
+        }
+      }
+#ifdef BNPVI_ABLATE_NOSTORE
+      if (ok && pv[0] + pv[1] == -123.f) {
+#else
+      if (ok) {
+#endif
+        *reinterpret_cast<float4*>(prow_out + kLT * T + 4 * kg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+        if (lrow_out)
+          *reinterpret_cast<float4*>(lrow_out + kLT * T + 4 * kg) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+      }
+    }
+  }
+  if (p.assign && ok && kg == 0) p.assign[n] = best;
+}
+
+// waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane)
+constexpr int fused_min_waves(int DP, int NT) {
+  return (NT <= 4 && DP <= 64) ? 3 : (NT <= 8 && DP <= 128) ? 2 : 1;
+}
+
+template <int DP, int NT, int PF, bool HARD, bool STATS>
+#ifdef BNPVI_NO_MINW
 __global__ __launch_bounds__(kEWaves * 64) void estep_fused_kernel(
+#else
+__global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_fused_kernel(
+#endif
     const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
     const f16x8* __restrict__ apack, const float* __restrict__ aavec, const float* __restrict__ a32,
     const float* __restrict__ scal /* [0] = 2^-ka */, const float* __restrict__ prior, float half_sz,
     float* __restrict__ phi, float* __restrict__ logphi, int32_t* __restrict__ assign,
     double* __restrict__ eslab) {
+  static_assert(PF == 1 || PF == 2, "one or two tiles in flight per wave");
   constexpr int S = DP / 32;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                  // [NT*S*2*64]
@@ -221,7 +373,8 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_fused_kernel(
   const int kg = lane >> 4;
   const int64_t ntiles = (N + kFT - 1) / kFT;
   const int64_t stride = (int64_t)gridDim.x * kEWaves;
-  LeafOperands lo_{a_lds, aa_lds, a32, scal[0]};
+  const LeafOperands lo_{a_lds, aa_lds, a32, scal[0]};
+  const FusedParams p{Z, ldz, vid, N, L, Lp, prior, half_sz, phi, logphi, assign};
 
   float s0[STATS ? NT : 1][4], s2[STATS ? NT : 1][4];
   if (STATS) {
@@ -232,107 +385,24 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_fused_kernel(
   }
 
   int64_t tile = (int64_t)blockIdx.x * kEWaves + wave;
-  float4 zA[S], zB[S];
-  if (tile < ntiles) load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
-
-  for (; tile < ntiles; tile += stride) {
-    const int64_t n = tile * kFT + j;
-    const bool ok = n < N;
-    const int64_t nn = ok ? n : N - 1;
-#ifdef BNPVI_ABLATE_NOPRIOR
-    const float* prow = nullptr;
-#else
-    const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp;
-#endif
-
-    f32x4 d2[NT];
-    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, lo_, lane, tiles_valid, L, d2);
-    // software prefetch of the next tile's rows: in flight during this tile's epilogue
-    if (tile + stride < ntiles) load_ztile<DP>(Z, ldz, (tile + stride) * kFT, N, lane, zA, zB);
-
-    // logits, running max and arg-max (first index wins ties)
-    f32x4 lg[NT];
-    float m = -INFINITY;
-    int best = 0x7fffffff;
-#pragma unroll
-    for (int T = 0; T < NT; ++T) {
-      float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool tv = T < tiles_valid;
-      if (!HARD && tv && prow) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
-      const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int leaf = kLT * T + 4 * kg + r;
-        float v;
-        if (HARD)
-          v = leaf < L ? -d2[T][r] : -INFINITY;
-        else
-          v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
-        lg[T][r] = v;
-        if (v > m) {
-          m = v;
-          best = leaf;
-        }
-      }
+  float4 zA0[S], zB0[S], zA1[PF == 2 ? S : 1], zB1[PF == 2 ? S : 1];
+  if (tile < ntiles) load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA0, zB0);
+  if constexpr (PF == 2) {
+    if (tile + stride < ntiles) load_ztile<DP>(Z, ldz, (tile + stride) * kFT, N, lane, zA1, zB1);
+  }
+  while (tile < ntiles) {
+    fused_tile<DP, NT, HARD, STATS>(p, lo_, tile, tile + PF * stride, ntiles, lane, tiles_valid, zA0, zB0,
+                                    s0, s2);
+    tile += stride;
+    if constexpr (PF == 2) {
+      if (tile >= ntiles) break;
+      // keep the two copies of the body apart: interleaved they need twice the registers
+      __builtin_amdgcn_sched_barrier(0);
+      fused_tile<DP, NT, HARD, STATS>(p, lo_, tile, tile + PF * stride, ntiles, lane, tiles_valid, zA1,
+                                      zB1, s0, s2);
+      tile += stride;
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) {
-      const float om = __shfl_xor(m, off);
-      const int ob = __shfl_xor(best, off);
-      if (om > m || (om == m && ob < best)) {
-        m = om;
-        best = ob;
-      }
-    }
-    float lse = 0.f;
-    if (!HARD) {
-      float ssum = 0.f;
-#pragma unroll
-      for (int T = 0; T < NT; ++T)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float x = lg[T][r] - m;
-          lg[T][r] = x;
-          ssum += __builtin_amdgcn_exp2f(x * kLog2e);
-        }
-      ssum += __shfl_xor(ssum, 16);
-      ssum += __shfl_xor(ssum, 32);
-      lse = __builtin_amdgcn_logf(ssum) * kLn2;
-    }
-
-    float* prow_out = phi + n * Lp;
-    float* lrow_out = logphi ? logphi + n * Lp : nullptr;
-#pragma unroll
-    for (int T = 0; T < NT; ++T) {
-      if (T < tiles_valid) {
-        float pv[4], lv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (HARD) {
-            const bool hit = (kLT * T + 4 * kg + r) == best;
-            pv[r] = hit ? 1.f : 0.f;
-            lv[r] = hit ? 0.f : -INFINITY;
-          } else {
-            lv[r] = lg[T][r] - lse;
-            pv[r] = __builtin_amdgcn_exp2f(lv[r] * kLog2e);
-          }
-          if (STATS && ok) {
-            s0[T][r] += pv[r];
-            s2[T][r] = fmaf(pv[r], d2[T][r], s2[T][r]);
-          }
-        }
-#ifdef BNPVI_ABLATE_NOSTORE
-        if (ok && pv[0] + pv[1] == -123.f) {
-#else
-        if (ok) {
-#endif
-          *reinterpret_cast<float4*>(prow_out + kLT * T + 4 * kg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-          if (lrow_out)
-            *reinterpret_cast<float4*>(lrow_out + kLT * T + 4 * kg) = make_float4(lv[0], lv[1], lv[2], lv[3]);
-        }
-      }
-    }
-    if (assign && ok && kg == 0) assign[n] = best;
   }
 
   if (STATS) {
@@ -393,7 +463,7 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
     float4 zA[S], zB[S];
     load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
     f32x4 d2[NT];
-    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, lo_, lane, tiles_valid, L - kLT * T0, d2);
+    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, -1, lo_, lane, tiles_valid, L - kLT * T0, d2);
     const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp + kLT * T0;
     float m = -INFINITY;
     int best = 0x7fffffff;

@@ -46,6 +46,13 @@ def main():
         ("estep_logphi", lambda: dev.estep(want_stats=False, want_logphi=True)),
         ("iteration", lambda: dev.iteration(want_estats=False)),
     ]
+    import ctypes as C
+
+    def kern_us(which):
+        ms, cnt = C.c_double(), C.c_int()
+        _lib.check(_lib.lib.bnpvi_profile_read(dev.ctx, which, C.byref(ms), C.byref(cnt)))
+        return 1e3 * ms.value / cnt.value if cnt.value else float("nan")
+
     out = []
     for name, fn in phases:
         fn()
@@ -58,6 +65,14 @@ def main():
         torch.cuda.synchronize()
         ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
         out.append("%s=%.1f" % (name, 1e3 * ts[len(ts) // 2]))
+        if name in ("leaf_stats", "leaf_stats_q", "estep", "estep_stats", "estep_logphi"):
+            # the main kernel alone (HIP events recorded around it inside the library)
+            _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 1))
+            for i in range(args.iters):
+                fn()
+            torch.cuda.synchronize()
+            out[-1] += "(k%.1f)" % kern_us(1 if name.startswith("leaf") else 0)
+            _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 0))
     print("%s N=%d D=%d L=%d  [us median] %s" % (args.tag or os.environ.get("BNPVI_LIB", "default").split("_")[-1],
                                                 args.n, args.d, L, " ".join(out)))
 
