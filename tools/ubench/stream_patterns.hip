@@ -3,7 +3,8 @@
 //   pattern 0: 1 KiB contiguous per wave-instruction (lane i -> 16 B at base + 16 i)
 //   pattern 1: 16 rows x 64 B per wave-instruction (lane (j = i & 15, kg = i >> 4) -> row j,
 //              bytes 16 kg of a 64-B piece) -- the MFMA 16x16x32 B-operand footprint
-// modes: r (read + reduce), w (write), c (read A, write B: the E-step's traffic shape)
+// modes: 0 read + reduce, 1 write, 2 copy (read A, write B: the E-step's traffic shape),
+//        3 copy with nontemporal stores, 4 copy with nontemporal loads and stores
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,6 +12,15 @@
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int MODE> __device__ __forceinline__ float4 ld(const float4* p) {
+  if (MODE == 4) { f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+  return *p;
+}
+template <int MODE> __device__ __forceinline__ void st(float4* p, float4 v) {
+  if (MODE >= 3) { f4 w = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(w, reinterpret_cast<f4*>(p)); }
+  else *p = v;
+}
 template <int PAT, int MODE, int PF>
 __global__ __launch_bounds__(256) void k(const float4* __restrict__ in, float4* __restrict__ out, long ntiles, float* sink) {
   // a tile = 16 rows x 256 B = 4 KiB = 256 float4; 4 instructions per wave per tile
@@ -29,7 +39,7 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ in, float4* 
     for (int p = 0; p < PF; ++p)
       if (t + p * stride < ntiles)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[p][i] = in[idx(t + p * stride, i)];
+        for (int i = 0; i < 4; ++i) buf[p][i] = ld<MODE>(in + idx(t + p * stride, i));
   }
   for (; t < ntiles; t += PF * stride) {
 #pragma unroll
@@ -43,14 +53,14 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ in, float4* 
       }
       if (MODE != 1 && tt + PF * stride < ntiles) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) buf[p][i] = in[idx(tt + PF * stride, i)];
+        for (int i = 0; i < 4; ++i) buf[p][i] = ld<MODE>(in + idx(tt + PF * stride, i));
       }
       if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc += v[i].x + v[i].y + v[i].z + v[i].w;
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[idx(tt, i)] = v[i];
+        for (int i = 0; i < 4; ++i) st<MODE>(out + idx(tt, i), v[i]);
       }
     }
   }
@@ -69,7 +79,7 @@ void run(const char* name, float4* a, float4* b, long ntiles, float* sink, int b
   CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= R;
-  const double bytes = (double)ntiles * 4096 * (MODE == 2 ? 2 : 1);
+  const double bytes = (double)ntiles * 4096 * (MODE >= 2 ? 2 : 1);
   printf("%-28s blocks=%5d  %8.1f us  %7.2f TB/s\n", name, blocks, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
 }
 
@@ -89,8 +99,10 @@ int main(int argc, char** argv) {
     run<1, 1, 1>("write 16x64B", a, b, ntiles, sink, blocks);
     run<0, 2, 1>("copy  contiguous pf1", a, b, ntiles, sink, blocks);
     run<1, 2, 1>("copy  16x64B     pf1", a, b, ntiles, sink, blocks);
-    run<0, 2, 2>("copy  contiguous pf2", a, b, ntiles, sink, blocks);
-    run<1, 2, 2>("copy  16x64B     pf2", a, b, ntiles, sink, blocks);
+    run<0, 3, 1>("copy  contiguous nt-st", a, b, ntiles, sink, blocks);
+    run<1, 3, 1>("copy  16x64B     nt-st", a, b, ntiles, sink, blocks);
+    run<0, 4, 1>("copy  contiguous nt-ld+st", a, b, ntiles, sink, blocks);
+    run<1, 4, 1>("copy  16x64B     nt-ld+st", a, b, ntiles, sink, blocks);
   }
   return 0;
 }
