@@ -60,6 +60,7 @@ EXPORTS = {
     "bnpvi_gamma_update": (_i, [_p, _p, _p, _i, _d, _p, _p]),
     "bnpvi_gamma_remap": (_i, [_p, _p, _i, _p, _i, _i, _p, _d, _p]),
     "bnpvi_prior_table": (_i, [_p, _p, _p, _p, _i, _d, _p, _p, _p, _p]),
+    "bnpvi_gamma_prior": (_i, [_p, _p, _p, _p, _i, _d, _d, _p, _p, _p]),
     "bnpvi_estep": (_i, [_p, _p, _p, _i, _p, _i64, _i, _p, _p, _d, _i, _p, _p, _p, _p, _p]),
     "bnpvi_kmeans_pass": (_i, [_p, _p, _i, _i64, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "bnpvi_remap_columns": (_i, [_p, _p, _i, _p, _i, _i64, _i, _p, _p, _p]),

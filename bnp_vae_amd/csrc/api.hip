@@ -244,7 +244,8 @@ int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_
       (rc = upload(t->node_of_leaf, &t->d_node_of_leaf)) ||
       (rc = upload(t->leaf_lo, &t->d_leaf_lo)) || (rc = upload(t->leaf_hi, &t->d_leaf_hi)) ||
       (rc = upload(t->child_ptr, &t->d_child_ptr)) || (rc = upload(t->child_idx, &t->d_child_idx)) ||
-      (rc = upload(t->level_nodes, &t->d_level_nodes))) {
+      (rc = upload(t->level_nodes, &t->d_level_nodes)) ||
+      (rc = upload(t->level_ptr, &t->d_level_ptr))) {
     bnpvi_tree_destroy(t);
     return rc;
   }
@@ -255,7 +256,7 @@ int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_
 int bnpvi_tree_destroy(bnpvi_tree* t) {
   if (!t) return BNPVI_OK;
   void* ptrs[] = {t->d_parent,  t->d_depth,     t->d_leaf_of_node, t->d_node_of_leaf, t->d_leaf_lo,
-                  t->d_leaf_hi, t->d_child_ptr, t->d_child_idx,    t->d_level_nodes};
+                  t->d_leaf_hi, t->d_child_ptr, t->d_child_idx,    t->d_level_nodes, t->d_level_ptr};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete t;
@@ -321,6 +322,14 @@ int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamm
   BNPVI_HIP(hipSetDevice(ctx->device));
   return launch_prior_table(ctx, tree, gamma, sigma, V, sZ, prior, on, before,
                             (hipStream_t)stream);
+}
+
+int bnpvi_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass, const double* sigma,
+                      int V, double gamma_hyper, double sZ, double* gamma, float* prior, void* stream) {
+  BNPVI_REQUIRE(ctx && tree && mass && sigma && gamma && prior, "bnpvi_gamma_prior: NULL argument");
+  BNPVI_REQUIRE(V >= 1, "bnpvi_gamma_prior: V=%d", V);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_gamma_prior(ctx, tree, mass, sigma, V, gamma_hyper, sZ, gamma, prior, (hipStream_t)stream);
 }
 
 int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,

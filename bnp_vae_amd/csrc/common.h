@@ -91,7 +91,8 @@ struct bnpvi_tree {
   // device copies
   int32_t *d_parent = nullptr, *d_depth = nullptr, *d_leaf_of_node = nullptr,
           *d_node_of_leaf = nullptr, *d_leaf_lo = nullptr, *d_leaf_hi = nullptr,
-          *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_level_nodes = nullptr;
+          *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_level_nodes = nullptr,
+          *d_level_ptr = nullptr;
 };
 
 // kernels' launchers (one per .hip file)
@@ -111,6 +112,10 @@ int launch_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass,
 int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
                        const double* sigma, int V, double sZ, float* prior, double* on,
                        double* before, hipStream_t s);
+
+// gamma-step + prior table in one launch (per-video work, no collective in between)
+int launch_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, const double* sigma, int V,
+                       double gamma_hyper, double sZ, double* gamma, float* prior, hipStream_t s);
 
 int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
                  const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,

@@ -6,29 +6,39 @@
 namespace bnpvi {
 
 // ------------------------------------------------------------------------------------------
-// Leaf operands.  Step 1 (one thread per padded leaf): fp32 row-major copy a32[Lp][DP] of the
+// Leaf operands.  Step 1 (one wave per padded leaf): fp32 row-major copy a32[Lp][DP] of the
 // leaves' alpha (fp64, [K][D], pre-order), ||alpha||^2 of the fp32-rounded values, and the
 // global max |alpha| (atomicMax on the bit pattern; non-negative floats order like ints).
 // Step 2 (one thread per 16-byte fragment): scaled exact hi/lo f16 split in MFMA operand
 // order: frag[((T*S+s)*2+part)*64+lane][e] = alpha[leaf 16T+(lane&15)][dim 32s+16(e>>2)+4(lane>>4)+(e&3)].
 // ------------------------------------------------------------------------------------------
-__global__ void leaf_rows_kernel(const double* __restrict__ alpha, int D, int DP,
-                                 const int32_t* __restrict__ node_of_leaf, int L, int Lp,
-                                 float* __restrict__ a32, float* __restrict__ aavec,
-                                 int* __restrict__ amax_bits) {
-  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void leaf_rows_kernel(const double* __restrict__ alpha, int D, int DP,
+                                                        const int32_t* __restrict__ node_of_leaf, int L,
+                                                        int Lp, float* __restrict__ a32,
+                                                        float* __restrict__ aavec,
+                                                        int* __restrict__ amax_bits) {
+  // one wave per padded leaf, lanes stride the dims
+  const int lane = threadIdx.x & 63;
+  const int leaf = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (leaf >= Lp) return;
   double aa = 0.0;
   float amax = 0.f;
   const double* a = leaf < L ? alpha + (int64_t)node_of_leaf[leaf] * D : nullptr;
-  for (int d = 0; d < DP; ++d) {
+  for (int d = lane; d < DP; d += 64) {
     const float f = (a && d < D) ? (float)a[d] : 0.f;
     a32[(int64_t)leaf * DP + d] = f;
     aa += (double)f * (double)f;
     amax = fmaxf(amax, fabsf(f));
   }
-  aavec[leaf] = (float)aa;
-  atomicMax(amax_bits, __float_as_int(amax));
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    aa += __shfl_xor(aa, off);
+    amax = fmaxf(amax, __shfl_xor(amax, off));
+  }
+  if (lane == 0) {
+    aavec[leaf] = (float)aa;
+    atomicMax(amax_bits, __float_as_int(amax));
+  }
 }
 
 __global__ void pack_leaves_kernel(const float* __restrict__ a32, int DP, int Lp,
@@ -229,7 +239,7 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
   float* scal = aavec + LpPack;          // [0] = 2^-ka, [1] = bits of max|alpha| (int)
   int* amax_bits = (int*)(scal + 1);
   BNPVI_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int), s));
-  hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 64)), dim3(64), 0, s, alpha, D, DP,
+  hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 4)), dim3(256), 0, s, alpha, D, DP,
                      t->d_node_of_leaf, t->L, LpPack, a32, aavec, amax_bits);
   BNPVI_LAUNCH_CHECK();
   {

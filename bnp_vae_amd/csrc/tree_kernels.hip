@@ -49,10 +49,54 @@ __global__ void node_params_level_kernel(const int32_t* __restrict__ level_nodes
   if (d == 0) sigma[k] = s;
 }
 
+// Small trees: every level in ONE launch by one workgroup (a level's writes are visible to the
+// next level's reads through the workgroup barrier; alpha is not __restrict__ here).
+__global__ __launch_bounds__(1024) void node_params_tree_kernel(
+    const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_ptr, int nlevels,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ leaf_of_node,
+    const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
+    const double* __restrict__ stats, int W, int D, double sB, double sZ,
+    const double* __restrict__ alpha0, double* alpha, double* __restrict__ sigma) {
+  for (int lev = nlevels - 1; lev >= 0; --lev) {
+    const int off = level_ptr[lev];
+    const int count = level_ptr[lev + 1] - off;
+    for (int e = threadIdx.x; e < count * D; e += blockDim.x) {
+      const int k = level_nodes[off + e / D];
+      const int d = e % D;
+      const int p = parent[k];
+      const double base = (p < 0) ? (alpha0 ? alpha0[d] : 0.0) : alpha[(int64_t)p * D + d];
+      const int l = leaf_of_node[k];
+      double s, a;
+      if (l >= 0) {
+        const double S0 = stats[(int64_t)l * W];
+        const double S1 = stats[(int64_t)l * W + 1 + d];
+        s = sB + S0 * sZ;
+        a = (base * sB + S1 * sZ) / s;
+      } else {
+        const int c0 = child_ptr[k], c1 = child_ptr[k + 1];
+        s = (1.0 + (double)(c1 - c0)) * sB;
+        double acc = base;
+        for (int c = c0; c < c1; ++c) acc += alpha[(int64_t)child_idx[c] * D + d];
+        a = acc * sB / s;
+      }
+      alpha[(int64_t)k * D + d] = a;
+      if (d == 0) sigma[k] = s;
+    }
+    __syncthreads();
+  }
+}
+
 int launch_node_params(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D,
                        double sB, double sZ, const double* alpha0, double* alpha, double* sigma,
                        hipStream_t s) {
   (void)ctx;
+  if ((int64_t)t->K * D <= 64 * 1024) {
+    hipLaunchKernelGGL(node_params_tree_kernel, dim3(1), dim3(1024), 0, s, t->d_level_nodes, t->d_level_ptr,
+                       t->nlevels, t->d_parent, t->d_leaf_of_node, t->d_child_ptr, t->d_child_idx, stats,
+                       W, D, sB, sZ, alpha0, alpha, sigma);
+    BNPVI_LAUNCH_CHECK();
+    return BNPVI_OK;
+  }
   for (int lev = t->nlevels - 1; lev >= 0; --lev) {
     const int off = t->level_ptr[lev];
     const int count = t->level_ptr[lev + 1] - off;
@@ -91,6 +135,12 @@ __device__ void block_inclusive_scan(double* a, int n, double* tmp) {
   __syncthreads();
 }
 
+template <bool DO_GAMMA, bool DO_PRIOR>
+static int launch_stick_wave(const bnpvi_tree* t, const double* mass, double* gamma, const double* sigma,
+                             int V, double gamma_hyper, double sZ, float* prior, double* on, double* before,
+                             hipStream_t s);
+constexpr int kWaveStickMaxK = 1024;   // trees up to this many nodes: one wave per video (below)
+
 // gamma[v][k] = (1 + mass of k's leaves, GAMMA + mass of all leaves before k's first leaf).
 // The reference's recursion (src/var_inf.py:395-413) hands every child "before(parent) + mass
 // of earlier siblings"; with leaves in DFS order that is the exclusive prefix at leaf_lo[k].
@@ -119,6 +169,9 @@ __global__ void gamma_kernel(const double* __restrict__ mass, int L, int K,
 int launch_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, int V,
                         double gamma_hyper, double* gamma, hipStream_t s) {
   (void)ctx;
+  if (t->K <= kWaveStickMaxK)
+    return launch_stick_wave<true, false>(t, mass, gamma, nullptr, V, gamma_hyper, 0.0, nullptr, nullptr,
+                                          nullptr, s);
   const int T = 256;
   const size_t lds = (size_t)(t->L + T) * sizeof(double);
   BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "gamma_update: L=%d too large for LDS", t->L);
@@ -220,10 +273,153 @@ __global__ void prior_kernel(const double* __restrict__ gamma, const double* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Trees of up to kWaveStickMaxK nodes: ONE WAVE per video does the gamma-step and/or the prior
+// table (no workgroup barriers; scans by lane segments + a shuffle scan).  LDS per wave:
+// Pm[L] (leaf-mass prefix), e0[K], P[K].
+// ------------------------------------------------------------------------------------------
+constexpr int kStickWaves = 4;
+
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// in-place inclusive scan of a[0..n) in LDS by one wave
+__device__ __forceinline__ void wave_inclusive_scan(double* a, int n, int lane) {
+  const int seg = (n + 63) >> 6;
+  const int b = lane * seg < n ? lane * seg : n;
+  const int e = (b + seg < n) ? b + seg : n;
+  double run = 0.0;
+  for (int j = b; j < e; ++j) {
+    run += a[j];
+    a[j] = run;
+  }
+  double incl = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const double t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  const double add = incl - run;
+  for (int j = b; j < e; ++j) a[j] += add;
+  wave_sync_lds();
+}
+
+template <bool DO_GAMMA, bool DO_PRIOR>
+__global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
+    const double* __restrict__ mass, double* gamma, const double* __restrict__ sigma,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ node_of_leaf,
+    const int32_t* __restrict__ leaf_lo, const int32_t* __restrict__ leaf_hi, int V, int K, int L, int Lp,
+    double gamma_hyper, double half_sz, float* __restrict__ prior, double* __restrict__ on_out,
+    double* __restrict__ before_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* Pm = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (L + 2 * K);
+  double* e0 = Pm + L;
+  double* P = e0 + K;
+  const int v = blockIdx.x * kStickWaves + wave;
+  if (v >= V) return;
+
+  if (DO_GAMMA) {
+    for (int l = lane; l < L; l += 64) Pm[l] = mass[(int64_t)v * L + l];
+    wave_sync_lds();
+    wave_inclusive_scan(Pm, L, lane);
+  }
+  for (int k = lane; k < K; k += 64) {
+    double2 g;
+    if (DO_GAMMA) {
+      const int lo = leaf_lo[k], hi = leaf_hi[k];
+      const double before = lo > 0 ? Pm[lo - 1] : 0.0;
+      const double upto = hi > 0 ? Pm[hi - 1] : 0.0;
+      g.x = 1.0 + (upto - before);
+      g.y = gamma_hyper + before;
+      reinterpret_cast<double2*>(gamma)[(int64_t)v * K + k] = g;
+    } else {
+      g = reinterpret_cast<const double2*>(gamma)[(int64_t)v * K + k];
+    }
+    if (DO_PRIOR) {
+      if (k == 0) {
+        e0[0] = 0.0;
+        P[0] = 0.0;
+      } else {
+        const double ps = digamma_pos(g.x + g.y);
+        e0[k] = digamma_pos(g.x) - ps;
+        P[k] = digamma_pos(g.y) - ps;
+      }
+    }
+  }
+  if (!DO_PRIOR) return;
+  wave_sync_lds();
+  wave_inclusive_scan(P, K, lane);
+
+  double best = -INFINITY;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int l = lane; l < Lp; l += 64) {
+      if (l >= L) {
+        if (pass == 1) prior[(int64_t)v * Lp + l] = -INFINITY;
+        continue;
+      }
+      const int k = node_of_leaf[l];
+      double on = 0.0, anc = 0.0;
+      if (k > 0) {
+        on = e0[k];
+        int a = parent[k];
+        while (a > 0) {
+          on += e0[a];
+          anc += P[a] - P[a - 1];
+          a = parent[a];
+        }
+      }
+      const double before = (k > 0 ? P[k - 1] : 0.0) - anc;
+      const double val = on + before - half_sz / sigma[k];
+      if (pass == 0) {
+        best = fmax(best, val);
+      } else {
+        prior[(int64_t)v * Lp + l] = (float)(val - best);
+        if (on_out) on_out[(int64_t)v * L + l] = on;
+        if (before_out) before_out[(int64_t)v * L + l] = before;
+      }
+    }
+    if (pass == 0) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+    }
+  }
+}
+
+template <bool DO_GAMMA, bool DO_PRIOR>
+static int launch_stick_wave(const bnpvi_tree* t, const double* mass, double* gamma, const double* sigma,
+                             int V, double gamma_hyper, double sZ, float* prior, double* on, double* before,
+                             hipStream_t s) {
+  const size_t lds = (size_t)kStickWaves * (t->L + 2 * t->K) * sizeof(double);
+  auto k = stick_wave_kernel<DO_GAMMA, DO_PRIOR>;
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k, dim3((unsigned)ceil_div(V, kStickWaves)), dim3(kStickWaves * 64), lds, s, mass, gamma,
+                     sigma, t->d_parent, t->d_node_of_leaf, t->d_leaf_lo, t->d_leaf_hi, V, t->K, t->L, t->Lp,
+                     gamma_hyper, 0.5 * sZ, prior, on, before);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
+int launch_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, const double* sigma, int V,
+                       double gamma_hyper, double sZ, double* gamma, float* prior, hipStream_t s) {
+  if (t->K <= kWaveStickMaxK)
+    return launch_stick_wave<true, true>(t, mass, gamma, sigma, V, gamma_hyper, sZ, prior, nullptr, nullptr, s);
+  int rc = launch_gamma_update(ctx, t, mass, V, gamma_hyper, gamma, s);
+  if (rc) return rc;
+  return launch_prior_table(ctx, t, gamma, sigma, V, sZ, prior, nullptr, nullptr, s);
+}
+
 int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
                        const double* sigma, int V, double sZ, float* prior, double* on,
                        double* before, hipStream_t s) {
   (void)ctx;
+  if (t->K <= kWaveStickMaxK)
+    return launch_stick_wave<false, true>(t, nullptr, const_cast<double*>(gamma), sigma, V, 0.0, sZ, prior,
+                                          on, before, s);
   const int T = 256;
   const size_t lds = (size_t)(2 * t->K + T) * sizeof(double);
   BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "prior_table: K=%d too large for LDS (max ~10000)", t->K);

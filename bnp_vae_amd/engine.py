@@ -212,6 +212,17 @@ class DeviceVI(object):
                                     self._stream()), "bnpvi_prior_table")
         return on, before
 
+    def gamma_prior(self):
+        """gamma-step and prior table back to back in one launch (src/var_inf.py:136-137)."""
+        K, Lp = self.tree.K, self.tree.Lp
+        if self.gamma is None or tuple(self.gamma.shape) != (self.V, K, 2):
+            self.gamma = self._empty((self.V, K, 2), torch.float64)
+        if self.prior is None or tuple(self.prior.shape) != (self.V, Lp):
+            self.prior = self._empty((self.V, Lp), torch.float32)
+        check(lib.bnpvi_gamma_prior(self.ctx, self.tree.handle, _ptr(self.mass), _ptr(self.sigma), self.V,
+                                    self.GAMMA, self.sZ, _ptr(self.gamma), _ptr(self.prior),
+                                    self._stream()), "bnpvi_gamma_prior")
+
     def estep(self, mode=_lib.ESTEP_SOFT, want_logphi=False, want_assign=False, want_stats=True):
         """src/var_inf.py:313-357, 383-393; HARD = one-hot nearest leaf (:126-132)."""
         Lp, L = self.tree.Lp, self.tree.L
@@ -239,8 +250,7 @@ class DeviceVI(object):
         self.leaf_stats(want_q=False, want_mass=True)
         self.allreduce_stats()
         self.node_params()
-        self.gamma_update()
-        self.prior_table()
+        self.gamma_prior()
         self.estep(want_stats=want_estats)
 
     # ------------------------------------------------------------------ split / merge support

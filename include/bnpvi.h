@@ -119,6 +119,14 @@ int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamm
                       const double* sigma_dev, int V, double sigma_z_sqrinv, float* prior_dev,
                       double* on_dev, double* before_dev, void* stream);
 
+/* ---- gamma-step + prior table in one launch: src/var_inf.py:395-416 then :359-381 --------
+ * Same results as bnpvi_gamma_update followed by bnpvi_prior_table (both outputs are written);
+ * one kernel instead of two when the caller runs them back to back, as one iteration of
+ * update_variational_parameters does (src/var_inf.py:136-137). */
+int bnpvi_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass_dev,
+                      const double* sigma_dev, int V, double gamma_hyper, double sigma_z_sqrinv,
+                      double* gamma_dev, float* prior_dev, void* stream);
+
 /* ---- E-step: src/var_inf.py:313-357,383-393 ---------------------------------------------
  * logit[n,l] = prior[vid[n],l] - 0.5*sZ*||z_n - alpha_l||_2   (UN-squared norm)
  * phi = softmax over leaves.  alpha_dev: double [K][D] (pre-order).

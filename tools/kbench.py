@@ -41,6 +41,7 @@ def main():
         ("node_params", dev.node_params),
         ("gamma_update", dev.gamma_update),
         ("prior_table", dev.prior_table),
+        ("gamma_prior", dev.gamma_prior),
         ("estep", lambda: dev.estep(want_stats=False)),
         ("estep_stats", lambda: dev.estep(want_stats=True)),
         ("estep_logphi", lambda: dev.estep(want_stats=False, want_logphi=True)),
