@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void leaf_rows_kernel(const double* __restrict
   if (lane == 0) {
     aavec[leaf] = (float)aa;
     atomicMax(amax_bits, __float_as_int(amax));
+    atomicMax(amax_bits + 1, __float_as_int((float)aa));   // non-negative floats order like ints
   }
 }
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void estep_normalize_kernel(
           if (HARD)
             dd = -xv[c];                                   // logit was -d^2
           else {
-            const float d = (prv[c] - xv[c]) * inv_half_sz;  // logit = prior - half_sz*d
+            const float d = (prv[c] * kLn2 - xv[c]) * inv_half_sz;  // logit = prior*ln2 - half_sz*d
             dd = d * d;
           }
           if (pv[c] != 0.f) {
@@ -236,9 +237,9 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
   f16x8* apack = (f16x8*)base;
   float* a32 = (float*)(base + img);
   float* aavec = (float*)(base + 2 * img);
-  float* scal = aavec + LpPack;          // [0] = 2^-ka, [1] = bits of max|alpha| (int)
+  float* scal = aavec + LpPack;          // [0] = 2^-ka, [1] = bits of max|alpha|, [2] = max ||alpha||^2
   int* amax_bits = (int*)(scal + 1);
-  BNPVI_HIP(hipMemsetAsync(amax_bits, 0, sizeof(int), s));
+  BNPVI_HIP(hipMemsetAsync(amax_bits, 0, 2 * sizeof(int), s));
   hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 4)), dim3(256), 0, s, alpha, D, DP,
                      t->d_node_of_leaf, t->L, LpPack, a32, aavec, amax_bits);
   BNPVI_LAUNCH_CHECK();

@@ -36,7 +36,7 @@ static int resident_blocks(const void* kern, size_t lds, int* out) {
 template <int DP, int NT, bool HARD, bool STATS>
 static int launch_fused(const EstepArgs& a) {
   // two Z tiles in flight per wave where a tile is cheap to hold (16 registers at DP = 64)
-  constexpr int PF = (DP <= 64 && NT <= 8) ? 2 : 1;
+  constexpr int PF = (DP <= 64 && NT <= 4) ? 2 : 1;
   const int L = a.tree->L, Lp = a.tree->Lp;
   const size_t lds = fused_lds_bytes<DP, NT>();
   auto k = estep_fused_kernel<DP, NT, PF, HARD, STATS>;

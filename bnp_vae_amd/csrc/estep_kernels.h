@@ -67,6 +67,7 @@ struct LeafOperands {
   const float* aa;       // ||alpha_l||^2 (fp32 of the fp32-rounded alpha), tile-relative
   const float* a32;      // row-major fp32 alpha [leaf][DP], tile-relative (refinement path)
   float inv_sa;          // 2^-ka, ka = scale exponent of alpha
+  float aamax;           // max_l ||alpha_l||^2
 };
 
 // ------------------------------------------------------------------------------------------
@@ -111,38 +112,54 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   if (next_row0 >= 0) load_ztile<DP>(Z, ldz, next_row0, N, lane, zA, zB);
 #endif
 
-#pragma unroll
-  for (int T = 0; T < NT; ++T) acc[T] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // every tile's MFMAs run unconditionally (operands of tiles past the padded leaves are zero)
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < S; ++s) {
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
-      if (T < tiles_valid) {
 #ifdef BNPVI_ABLATE_NOMFMA
-        acc[T][s & 3] += (float)bh[s][0] + (float)bl[s][1];
+      acc[T][s & 3] = (s ? acc[T][s & 3] : 0.f) + (float)bh[s][0] + (float)bl[s][1];
 #else
-        const f16x8 ah = lo_.a[((T * S + s) * 2 + 0) * 64 + lane];
-        const f16x8 al = lo_.a[((T * S + s) * 2 + 1) * 64 + lane];
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], acc[T], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[s], acc[T], 0, 0, 0);
-        acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], acc[T], 0, 0, 0);
+      const f16x8 ah = lo_.a[((T * S + s) * 2 + 0) * 64 + lane];
+      const f16x8 al = lo_.a[((T * S + s) * 2 + 1) * 64 + lane];
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], s ? acc[T] : zero4, 0, 0, 0);
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[s], acc[T], 0, 0, 0);
+      acc[T] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], acc[T], 0, 0, 0);
 #endif
-      }
     }
   }
-  // d^2 in place; remember which entries are too cancelled to trust
+  // d^2 in place.  Cancellation check: an entry below kRefineRel*(||z||^2+||a||^2)^2 cannot be
+  // trusted; the common case is screened with ONE compare per lane (min d^2 against the bound
+  // for the largest ||a||^2), the per-entry test runs only for waves that fail the screen.
   const float unscale = -2.f * pow2f(-kz) * lo_.inv_sa;
-  unsigned pend = 0u;
+  float dmin = INFINITY;
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     const float4 aa4 = *reinterpret_cast<const float4*>(lo_.aa + kLT * T + 4 * kg);
     const float aav[4] = {aa4.x, aa4.y, aa4.z, aa4.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float sn = zz + aav[r];
-      const float v = fmaxf(fmaf(unscale, acc[T][r], sn), 0.f);
-      if ((v < kRefineRel * sn * sn) && (kLT * T + 4 * kg + r < lvalid)) pend |= 1u << ((T * 4 + r) & 31);
+      const float v = fmaxf(fmaf(unscale, acc[T][r], zz + aav[r]), 0.f);
+      dmin = fminf(dmin, v);
       acc[T][r] = v;
+    }
+  }
+  const float snmax = zz + lo_.aamax;
+  unsigned pend = 0u;
+  if (__ballot(dmin < kRefineRel * snmax * snmax) != 0ull) {
+#pragma unroll
+    for (int T = 0; T < NT; ++T) {
+      if (T < tiles_valid) {
+        const float4 aa4 = *reinterpret_cast<const float4*>(lo_.aa + kLT * T + 4 * kg);
+        const float aav[4] = {aa4.x, aa4.y, aa4.z, aa4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sn = zz + aav[r];
+          if ((acc[T][r] < kRefineRel * sn * sn) && (kLT * T + 4 * kg + r < lvalid))
+            pend |= 1u << ((T * 4 + r) & 31);
+        }
+      }
     }
   }
   // rare path, one flagged (frame, leaf) pair at a time: the whole wave computes that pair's
@@ -220,27 +237,16 @@ struct FusedParams {
   int32_t* assign;
 };
 
-template <int DP, int NT, bool HARD, bool STATS>
-__device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOperands& lo_, int64_t tile,
-                                           int64_t next_tile, int64_t ntiles, int lane, int tiles_valid,
-                                           float4 (&zA)[DP / 32], float4 (&zB)[DP / 32],
-                                           float (&s0)[STATS ? NT : 1][4], float (&s2)[STATS ? NT : 1][4]) {
-  const int j = lane & 15;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Generic epilogue of a tile (hard mode, or log phi / arg-max asked for): natural-log logits,
+// arg-max tracking, phi = exp(log phi).
+template <int NT, bool HARD, bool STATS>
+__device__ __forceinline__ void tile_epilogue_generic(const FusedParams& p, int64_t n, bool ok, int lane,
+                                                      int tiles_valid, const float* prow, f32x4 (&d2)[NT],
+                                                      float (&s0)[STATS ? NT : 1][4],
+                                                      float (&s2)[STATS ? NT : 1][4]) {
   const int kg = lane >> 4;
-  const int64_t n = tile * kFT + j;
-  const bool ok = n < p.N;
-  const int64_t nn = ok ? n : p.N - 1;
-#ifdef BNPVI_ABLATE_NOPRIOR
-  const float* prow = nullptr;
-#else
-  const float* prow = HARD ? nullptr : p.prior + (int64_t)p.vid[nn] * p.Lp;
-#endif
-
-  f32x4 d2[NT];
-  tile_distances<DP, NT>(p.Z, p.ldz, tile * kFT, p.N, zA, zB, next_tile < ntiles ? next_tile * kFT : -1,
-                         lo_, lane, tiles_valid, p.L, d2);
-
-  // logits, running max and arg-max (first index wins ties)
   f32x4 lg[NT];
   float m = -INFINITY;
   int best = 0x7fffffff;
@@ -256,8 +262,8 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
       float v;
       if (HARD)
         v = leaf < p.L ? -d2[T][r] : -INFINITY;
-      else
-        v = tv ? fmaf(-p.half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
+      else      // the prior table is kept in log2 units
+        v = tv ? fmaf(-p.half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r] * kLn2) : -INFINITY;
       lg[T][r] = v;
       if (v > m) {
         m = v;
@@ -274,14 +280,7 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
       best = ob;
     }
   }
-  // soft mode: e = exp(logit - max) once per entry and phi = e / sum; when log phi is asked
-  // for, the slot keeps logit - max instead and phi = exp(log phi) (a second exponential)
-#ifdef BNPVI_TEST_NOLOG
-  const bool want_log = false;
-#else
-  const bool want_log = p.logphi != nullptr;
-#endif
-  float lse = 0.f, inv = 0.f;
+  float lse = 0.f;
   if (!HARD) {
     float ssum = 0.f;
 #pragma unroll
@@ -289,18 +288,15 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float x = lg[T][r] - m;
-        const float e = __builtin_amdgcn_exp2f(x * kLog2e);
-        ssum += e;
-        lg[T][r] = want_log ? x : e;
+        lg[T][r] = x;
+        ssum += __builtin_amdgcn_exp2f(x * kLog2e);
       }
     ssum += __shfl_xor(ssum, 16);
     ssum += __shfl_xor(ssum, 32);
     lse = __builtin_amdgcn_logf(ssum) * kLn2;
-    inv = __builtin_amdgcn_rcpf(ssum);
   }
-
   float* prow_out = p.phi + n * p.Lp;
-  float* lrow_out = want_log ? p.logphi + n * p.Lp : nullptr;
+  float* lrow_out = p.logphi ? p.logphi + n * p.Lp : nullptr;
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     if (T < tiles_valid) {
@@ -311,23 +307,16 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
           const bool hit = (kLT * T + 4 * kg + r) == best;
           pv[r] = hit ? 1.f : 0.f;
           lv[r] = hit ? 0.f : -INFINITY;
-        } else if (want_log) {
+        } else {
           lv[r] = lg[T][r] - lse;
           pv[r] = __builtin_amdgcn_exp2f(lv[r] * kLog2e);
-        } else {
-          lv[r] = 0.f;
-          pv[r] = lg[T][r] * inv;
         }
         if (STATS && ok) {
           s0[T][r] += pv[r];
           s2[T][r] = fmaf(pv[r], d2[T][r], s2[T][r]);
         }
       }
-#ifdef BNPVI_ABLATE_NOSTORE
-      if (ok && pv[0] + pv[1] == -123.f) {
-#else
       if (ok) {
-#endif
         *reinterpret_cast<float4*>(prow_out + kLT * T + 4 * kg) = make_float4(pv[0], pv[1], pv[2], pv[3]);
         if (lrow_out)
           *reinterpret_cast<float4*>(lrow_out + kLT * T + 4 * kg) = make_float4(lv[0], lv[1], lv[2], lv[3]);
@@ -335,6 +324,108 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
     }
   }
   if (p.assign && ok && kg == 0) p.assign[n] = best;
+}
+
+// Fast epilogue (soft responsibilities only, the production path of compute_phi): log2-domain
+// logits straight from the log2-unit prior table, one exponential per entry, phi = e / sum,
+// pairs of entries on the packed fp32 pipe, one store block per frame.
+template <int NT, int TV, bool STATS>
+__device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t n, bool ok, int lane,
+                                                   int tiles_valid, const float* prow, f32x4 (&d2)[NT],
+                                                   float (&s0)[STATS ? NT : 1][4],
+                                                   float (&s2)[STATS ? NT : 1][4]) {
+  const int kg = lane >> 4;
+  const float c2 = -p.half_sz * kLog2e;
+  f32x4 lg[NT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    float4 p4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (TV > 0 || T < tiles_valid) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+    lg[T][0] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][0]), p4.x);
+    lg[T][1] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][1]), p4.y);
+    lg[T][2] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][2]), p4.z);
+    lg[T][3] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][3]), p4.w);
+    m = fmaxf(fmaxf(m, lg[T][0]), lg[T][1]);
+    m = fmaxf(fmaxf(m, lg[T][2]), lg[T][3]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 16));
+  m = fmaxf(m, __shfl_xor(m, 32));
+  f32x2 ss = {0.f, 0.f};
+  const f32x2 m2 = {m, m};
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 x = (f32x2){lg[T][2 * h], lg[T][2 * h + 1]} - m2;
+      const f32x2 e = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+      ss += e;
+      lg[T][2 * h] = e[0];
+      lg[T][2 * h + 1] = e[1];
+    }
+  }
+  float ssum = ss[0] + ss[1];
+  ssum += __shfl_xor(ssum, 16);
+  ssum += __shfl_xor(ssum, 32);
+  // lanes past the last frame get phi = 0: nothing enters the statistics, nothing is stored
+  const float inv = ok ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+  const f32x2 inv2 = {inv, inv};
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x2 pv = (f32x2){lg[T][2 * h], lg[T][2 * h + 1]} * inv2;
+      lg[T][2 * h] = pv[0];
+      lg[T][2 * h + 1] = pv[1];
+      if (STATS) {
+        f32x2 a0 = {s0[T][2 * h], s0[T][2 * h + 1]};
+        f32x2 a2 = {s2[T][2 * h], s2[T][2 * h + 1]};
+        const f32x2 dd = {d2[T][2 * h], d2[T][2 * h + 1]};
+        a0 += pv;
+        a2 += pv * dd;
+        s0[T][2 * h] = a0[0];
+        s0[T][2 * h + 1] = a0[1];
+        s2[T][2 * h] = a2[0];
+        s2[T][2 * h + 1] = a2[1];
+      }
+    }
+  }
+#ifdef BNPVI_ABLATE_NOSTORE
+  if (ok && lg[0][0] + lg[0][1] == -123.f) {
+#else
+  if (ok) {
+#endif
+    float* prow_out = p.phi + n * p.Lp + 4 * kg;
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+      if (TV > 0 || T < tiles_valid)
+        *reinterpret_cast<float4*>(prow_out + kLT * T) = make_float4(lg[T][0], lg[T][1], lg[T][2], lg[T][3]);
+  }
+}
+
+template <int DP, int NT, bool HARD, bool STATS>
+__device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOperands& lo_, int64_t tile,
+                                           int64_t next_tile, int64_t ntiles, int lane, int tiles_valid,
+                                           float4 (&zA)[DP / 32], float4 (&zB)[DP / 32],
+                                           float (&s0)[STATS ? NT : 1][4], float (&s2)[STATS ? NT : 1][4]) {
+  // NT <= 4 is only dispatched with every tile valid (Lp = 16 NT): compile-time tile count there
+  constexpr int TV = NT <= 4 ? NT : 0;
+  const int j = lane & 15;
+  const int64_t n = tile * kFT + j;
+  const bool ok = n < p.N;
+  const int64_t nn = ok ? n : p.N - 1;
+#ifdef BNPVI_ABLATE_NOPRIOR
+  const float* prow = p.prior;
+#else
+  const float* prow = HARD ? nullptr : p.prior + (int64_t)p.vid[nn] * p.Lp;
+#endif
+  f32x4 d2[NT];
+  tile_distances<DP, NT>(p.Z, p.ldz, tile * kFT, p.N, zA, zB, next_tile < ntiles ? next_tile * kFT : -1,
+                         lo_, lane, tiles_valid, p.L, d2);
+  if (HARD || p.logphi != nullptr || p.assign != nullptr)
+    tile_epilogue_generic<NT, HARD, STATS>(p, n, ok, lane, tiles_valid, prow, d2, s0, s2);
+  else
+    tile_epilogue_soft<NT, TV, STATS>(p, n, ok, lane, tiles_valid, prow, d2, s0, s2);
 }
 
 // waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane)
@@ -361,7 +452,8 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
   double* st_lds = reinterpret_cast<double*>(aa_lds + kLT * NT);      // [16*NT][2]
   const int tiles_valid = Lp / kLT;
 
-  for (int e = threadIdx.x; e < tiles_valid * S * 2 * 64; e += blockDim.x) a_lds[e] = apack[e];
+  for (int e = threadIdx.x; e < NT * S * 2 * 64; e += blockDim.x)
+    a_lds[e] = e < tiles_valid * S * 2 * 64 ? apack[e] : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
   for (int e = threadIdx.x; e < kLT * NT; e += blockDim.x) aa_lds[e] = e < Lp ? aavec[e] : 0.f;
   if (STATS)
     for (int e = threadIdx.x; e < 2 * kLT * NT; e += blockDim.x) st_lds[e] = 0.0;
@@ -373,7 +465,7 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
   const int kg = lane >> 4;
   const int64_t ntiles = (N + kFT - 1) / kFT;
   const int64_t stride = (int64_t)gridDim.x * kEWaves;
-  const LeafOperands lo_{a_lds, aa_lds, a32, scal[0]};
+  const LeafOperands lo_{a_lds, aa_lds, a32, scal[0], scal[2]};
   const FusedParams p{Z, ldz, vid, N, L, Lp, prior, half_sz, phi, logphi, assign};
 
   float s0[STATS ? NT : 1][4], s2[STATS ? NT : 1][4];
@@ -453,7 +545,8 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
   int tiles_valid = Lp / kLT - T0;
   tiles_valid = tiles_valid > NT ? NT : tiles_valid;
   const int64_t ntiles = (N + kFT - 1) / kFT;
-  LeafOperands lo_{apack + (int64_t)T0 * S * 2 * 64, aavec + kLT * T0, a32 + (int64_t)kLT * T0 * DP, scal[0]};
+  LeafOperands lo_{apack + (int64_t)T0 * S * 2 * 64, aavec + kLT * T0, a32 + (int64_t)kLT * T0 * DP, scal[0],
+                   scal[2]};
 
   for (int64_t tile = (int64_t)blockIdx.x * kEWaves + wave; tile < ntiles;
        tile += (int64_t)gridDim.x * kEWaves) {
@@ -480,7 +573,7 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
         if (HARD)
           v = leaf < L ? -d2[T][r] : -INFINITY;
         else
-          v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r]) : -INFINITY;
+          v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r] * kLn2) : -INFINITY;
         d2[T][r] = v;
         if (v > m) {
           m = v;

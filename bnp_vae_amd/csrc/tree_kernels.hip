@@ -254,7 +254,7 @@ __global__ void prior_kernel(const double* __restrict__ gamma, const double* __r
       if (pass == 0) {
         best = fmax(best, val);
       } else {
-        prior[(int64_t)v * Lp + l] = (float)(val - best);
+        prior[(int64_t)v * Lp + l] = (float)((val - best) * 1.4426950408889634);   // log2 units
         if (on_out) on_out[(int64_t)v * L + l] = on;
         if (before_out) before_out[(int64_t)v * L + l] = before;
       }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
       if (pass == 0) {
         best = fmax(best, val);
       } else {
-        prior[(int64_t)v * Lp + l] = (float)(val - best);
+        prior[(int64_t)v * Lp + l] = (float)((val - best) * 1.4426950408889634);   // log2 units
         if (on_out) on_out[(int64_t)v * L + l] = on;
         if (before_out) before_out[(int64_t)v * L + l] = before;
       }

@@ -112,7 +112,9 @@ int bnpvi_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mas
  * prior_dev : float [V][ldp], ldp = bnpvi_padded_leaves(L).  Row v, column l holds
  *             on[l][v] + before[l][v] - 0.5*sZ/sigma[leaf l]  minus the row maximum
  *             (softmax over leaves is shift-invariant per frame; the shift is applied in
- *             fp64 before rounding to fp32).  Padded columns hold -inf.
+ *             fp64 before rounding to fp32), in LOG2 units (multiplied by log2 e: the E-step
+ *             exponentiates with exp2).  Padded columns hold -inf.  The table is private to
+ *             the (bnpvi_prior_table | bnpvi_gamma_prior, bnpvi_estep) pair.
  * on_dev / before_dev: optional double [V][L] unshifted tables (NULL to skip) -- the two
  *             dicts compute_gamma_sum_on / compute_gamma_sum_before return. */
 int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamma_dev,

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--levels", type=int, default=2)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--only", default="", help="comma-separated phases to run (default: all)")
     args = ap.parse_args()
     import torch
     from bench import regular_tree, make_latents
@@ -55,6 +56,8 @@ def main():
         return 1e3 * ms.value / cnt.value if cnt.value else float("nan")
 
     out = []
+    if args.only:
+        phases = [p for p in phases if p[0] in args.only.split(",")]
     for name, fn in phases:
         fn()
         torch.cuda.synchronize()
