@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import dist as vdist
 from ._lib import lib, check
 
 
@@ -178,9 +179,7 @@ class DeviceVI(object):
 
     def allreduce_stats(self):
         """The single collective of an iteration (RCCL all-reduce, sum, fp64)."""
-        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
-            torch.distributed.all_reduce(self.stats, op=torch.distributed.ReduceOp.SUM,
-                                         group=self.group)
+        vdist.allreduce_sum_(self.stats, self.group)
 
     def node_params(self):
         """sigma / alpha update on the tree (src/var_inf.py:265-297)."""
@@ -241,9 +240,7 @@ class DeviceVI(object):
         return logphi, assign
 
     def allreduce_estats(self):
-        if self.group is not None and torch.distributed.get_world_size(self.group) > 1:
-            torch.distributed.all_reduce(self.estats, op=torch.distributed.ReduceOp.SUM,
-                                         group=self.group)
+        vdist.allreduce_sum_(self.estats, self.group)
 
     def iteration(self, want_estats=True):
         """One VI iteration: M-step -> gamma-step -> prior table -> E-step (var_inf.py:135-137)."""
@@ -259,8 +256,7 @@ class DeviceVI(object):
 
         Returns the chosen row indices (single process / rank-local frames)."""
         N = self.N
-        dist = torch.distributed
-        multi = self.group is not None and dist.get_world_size(self.group) > 1
+        multi = vdist.world_size(self.group) > 1
         dist2 = self._empty((max(N, 1),), torch.float32)
         best_row = torch.zeros((1,), dtype=torch.int64, device=self.device)
         best_score = torch.zeros((1,), dtype=torch.float32, device=self.device)
@@ -277,20 +273,14 @@ class DeviceVI(object):
             else:
                 row, score = 0, -1.0
             if multi:
-                # arg-max all-reduce: (score, global row), lowest row wins ties (np.argmax)
-                me = dist.get_rank(self.group)
-                mine = torch.tensor([score, float(self.row_offset + row), float(me)],
-                                    dtype=torch.float64, device=self.device)
-                allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(self.group))]
-                dist.all_gather(allv, mine, group=self.group)
-                cand = sorted(((-float(a[0]), float(a[1]), int(a[2])) for a in allv))
-                # all-zero scores: every rank reports its local row 0, so the lowest global
-                # row (index 0, as normalize()'s uniform fallback gives) wins; empty ranks lose
-                _negs, grow, owner = cand[0]
-                if owner == me:
-                    centre.copy_(self.Z[int(grow) - self.row_offset])
-                dist.broadcast(centre, src=dist.get_global_rank(self.group, owner), group=self.group)
-                rows.append(int(grow))
+                # arg-max over ranks: (score, global row), lowest row wins ties (np.argmax).  With
+                # all-zero scores every rank reports its local row 0, so global row 0 wins (the
+                # uniform fallback of normalize()); empty ranks (score -1) lose.
+                grow, owner = vdist.select_argmax(score, self.row_offset + row, self.group, self.device)
+                if owner == torch.distributed.get_rank(self.group):
+                    centre.copy_(self.Z[grow - self.row_offset])
+                vdist.broadcast_from(centre, owner, self.group)
+                rows.append(grow)
             else:
                 centre.copy_(self.Z[row])
                 rows.append(row)

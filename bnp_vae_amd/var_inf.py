@@ -96,11 +96,9 @@ class VarInf(object):
         if not self._multi():
             return n
         if self._N_global is None or self._N_global[0] != n:
-            import torch
-            import torch.distributed as dist
-            t = torch.tensor([n], dtype=torch.int64, device=self._engine().device)
-            dist.all_reduce(t, group=self._group)
-            self._N_global = (n, int(t.item()))
+            from . import dist as vdist
+            total, _off = vdist.global_count(n, self._group, self._engine().device)
+            self._N_global = (n, total)
         return self._N_global[1]
 
     def _new_node(self, node_id, parent):
@@ -148,12 +146,8 @@ class VarInf(object):
                              % (Z.shape, len(self.vidid_frameid_to_idx)))
         dev.set_latents(Z, self._video_index(), len(self.vidid_to_idx))
         if self._multi():
-            import torch
-            import torch.distributed as dist
-            mine = torch.tensor([Z.shape[0]], dtype=torch.int64, device=dev.device)
-            allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(self._group))]
-            dist.all_gather(allv, mine, group=self._group)
-            self._row_offset = int(sum(int(a.item()) for a in allv[:dist.get_rank(self._group)]))
+            from . import dist as vdist
+            _total, self._row_offset = vdist.global_count(Z.shape[0], self._group, dev.device)
         dev.row_offset = self._row_offset
         self._Z_host = Z
         self._mass_key = None
