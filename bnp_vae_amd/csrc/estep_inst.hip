@@ -1,6 +1,9 @@
 // One translation unit per padded latent dim (compiled with -DBNPVI_DP=<32|64|128|256>) so the
 // unrolled MFMA bodies build in parallel.  See estep_kernels.h.
-#include "estep_kernels.h"
+#include <stdlib.h>
+#include <string.h>
+
+#include "estep_rows.h"
 
 #ifndef BNPVI_DP
 #error "compile with -DBNPVI_DP=<padded latent dim>"
@@ -102,11 +105,55 @@ static int run_streamed(const EstepArgs& a) {
   return estep_finish_streamed(a, part, nchunk);
 }
 
+// Two-pass row kernel (estep_rows.h): soft mode, packed leaf operands resident in LDS.
+template <int DP>
+static bool rows_fits(const EstepArgs& a) {
+  const int NTp = round_up(a.tree->Lp / kLT, kRChunk);
+  return a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr &&
+         RowsLds<DP>::bytes(NTp, a.estats != nullptr) <= (size_t)kMaxLdsBytes;
+}
+
+template <int DP, bool STATS>
+static int launch_rows(const EstepArgs& a) {
+  const int L = a.tree->L, Lp = a.tree->Lp;
+  const int NTp = round_up(Lp / kLT, kRChunk);
+  const size_t lds = RowsLds<DP>::bytes(NTp, STATS);
+  auto k = estep_rows_kernel<DP, STATS>;
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((size_t)kMaxLdsBytes / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);          // 8-wave workgroups, <= 4 waves/SIMD
+  const int64_t ntiles = ceil_div(a.N, kFT);
+  // contiguous tile ranges per workgroup; at most 512 tiles (8192 frames) so that the fp32
+  // statistics table of a workgroup stays exact enough before its promotion to fp64
+  int64_t tpw = ceil_div(ntiles, (int64_t)a.ctx->num_cu * per_cu);
+  tpw = round_up((int)(tpw < 8 ? 8 : (tpw > 512 ? 512 : tpw)), kRWaves);
+  const int64_t blocks = ceil_div(ntiles, tpw);
+  double* eslab = nullptr;
+  if (STATS) {
+    int rc = a.ctx->slabs.ensure((size_t)blocks * 2 * L * sizeof(double));
+    if (rc) return rc;
+    eslab = (double*)a.ctx->slabs.ptr;
+  }
+  const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kRWaves * 64), lds, a.stream, a.Z, a.ldz, a.vid, a.N, L,
+                     Lp, NTp, a.apack, a.aavec, a.a32, a.scal, a.prior, a.half_sz, a.phi, a.logphi, eslab,
+                     (int)tpw);
+  if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
+  BNPVI_LAUNCH_CHECK();
+  if (STATS) return estep_reduce_slabs(a, eslab, (int)blocks);
+  return BNPVI_OK;
+}
+
 template <>
 int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   constexpr int DP = BNPVI_DP;
   const int Lp = a.tree->Lp;
   const bool hard_stats = a.mode == BNPVI_ESTEP_HARD && a.estats != nullptr;
+  const char* force = getenv("BNPVI_ESTEP_PATH");         // development switch: "rows" | "fused"
+  const bool want_rows = force ? strcmp(force, "rows") == 0 : Lp > 64;
+  if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
+    return a.estats ? launch_rows<DP, true>(a) : launch_rows<DP, false>(a);
   if (!hard_stats) {
     // smallest instantiated tile count that covers the padded leaves and fits the LDS
     if (Lp <= 32 && fused_lds_bytes<DP, 2>() <= (size_t)kMaxLdsBytes) return run_fused<DP, 2>(a);

@@ -213,6 +213,37 @@ def test_iteration_against_oracle(N, D, bf, levels, fpv):
         np.testing.assert_allclose(S0.sum(), N, rtol=1e-6)
 
 
+@pytest.mark.parametrize("N,D,bf,levels,fpv", [
+    (3000, 64, 8, 3, [100, 57]),      # BASELINE config 3 shape (L=512): two-pass row kernel
+    (2000, 32, 5, 3, [256]),          # L=125 (padded 128)
+    (1500, 128, 6, 3, [300, 41]),     # L=216, D=128: leaf operands just fit the LDS
+    (2100, 64, 9, 2, [64]),           # L=81 (padded 96): last 64-leaf chunk half empty
+])
+def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
+    """Trees with more than 64 leaves take the two-pass row kernel (estep_rows.h) when neither
+    hard mode nor the arg-max is asked for: phi, log phi and the split/merge statistics."""
+    ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=9)
+    for leaf, col in zip(vi._dfs_leaves(), snapshot(ora)['phi'].T):
+        leaf.phi = col.reshape(-1, 1)
+    for it in range(2):
+        ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
+        ora.compute_gamma(); vi.compute_gamma()
+        ora.compute_phi(Z)
+        logphi, _ = vi.compute_phi(Z, want_logphi=True)
+        L = ora.last_log_phi.shape[1]
+        np.testing.assert_allclose(logphi.cpu().numpy()[:, :L], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
+        po, pp = snapshot(ora)['phi'], snapshot(vi)['phi']
+        np.testing.assert_allclose(pp, po, rtol=0, atol=PHI_ATOL)
+        np.testing.assert_allclose(pp.sum(axis=1), 1.0, atol=1e-5)
+        S0, S2 = vi._leaf_moments()
+        d2 = ((Z[:, None, :].astype(np.float64) - np.asarray([l.alpha for l in ora.leaves()])[None]) ** 2).sum(-1)
+        np.testing.assert_allclose(S0, po.sum(0), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(S2, (po * d2).sum(0), rtol=1e-4, atol=1e-3)
+    # without log phi (the production call) the same phi must come out
+    vi.compute_phi(Z)
+    np.testing.assert_allclose(snapshot(vi)['phi'], pp, rtol=0, atol=1e-6)
+
+
 def test_frames_coinciding_with_leaf_means():
     """Right after a split the new leaf means ARE data rows (weighted_kmeans): d = 0 exactly.
     The fp32 expansion cancels catastrophically there; the kernel must fall back to direct
@@ -226,6 +257,19 @@ def test_frames_coinciding_with_leaf_means():
     ora.compute_phi(Z)
     logphi, _ = vi.compute_phi(Z, want_logphi=True)
     np.testing.assert_allclose(logphi.cpu().numpy()[:, :64], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
+
+
+def test_frames_coinciding_with_leaf_means_row_kernel():
+    """Same cancellation case through the two-pass row kernel (L = 512)."""
+    N, D, bf, levels = 2048, 64, 8, 3
+    ora, vi, Z = _regular_case(N, D, bf, levels, [256], seed=11)
+    rows = np.arange(0, 512) * 3
+    for vobj, leaves in ((ora, ora.leaves()), (vi, vi._dfs_leaves())):
+        for r, leaf in zip(rows, leaves):
+            leaf.alpha = Z[r].astype(np.float64)
+    ora.compute_phi(Z)
+    logphi, _ = vi.compute_phi(Z, want_logphi=True)
+    np.testing.assert_allclose(logphi.cpu().numpy()[:, :512], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
 
 
 def test_ragged_and_tiny_inputs():
