@@ -122,12 +122,13 @@ static int launch_rows(const EstepArgs& a) {
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((size_t)kMaxLdsBytes / lds);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu);          // 8-wave workgroups, <= 4 waves/SIMD
+  per_cu = per_cu < 1 ? 1 : (per_cu > 32 / kRWaves ? 32 / kRWaves : per_cu);
   const int64_t ntiles = ceil_div(a.N, kFT);
   // contiguous tile ranges per workgroup; at most 512 tiles (8192 frames) so that the fp32
   // statistics table of a workgroup stays exact enough before its promotion to fp64
   int64_t tpw = ceil_div(ntiles, (int64_t)a.ctx->num_cu * per_cu);
-  tpw = round_up((int)(tpw < 8 ? 8 : (tpw > 512 ? 512 : tpw)), kRWaves);
+  tpw = round_up((int)(tpw < kRWaves ? kRWaves : tpw), kRWaves);
+  if (tpw > 512 / kRWaves * kRWaves) tpw = 512 / kRWaves * kRWaves;
   const int64_t blocks = ceil_div(ntiles, tpw);
   double* eslab = nullptr;
   if (STATS) {

@@ -61,6 +61,36 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, float s
   }
 }
 
+// ---- cross-lane reductions on the VALU (no LDS round trips) ---------------------------------
+// The 4 lanes {l, l^16, l^32, l^48} (same column of the four 16-lane rows): permlane16/32 swaps.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float cols4_sum(float x) {
+  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float cols4_max(float x) {
+  u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// The 16 lanes of a row: DPP row rotations by 1, 2, 4, 8.
+#define BNPVI_ROR(v, n) __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x120 + (n), 0xf, 0xf, false))
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, BNPVI_ROR(v, 1));
+  v = fmaxf(v, BNPVI_ROR(v, 2));
+  v = fmaxf(v, BNPVI_ROR(v, 4));
+  return fmaxf(v, BNPVI_ROR(v, 8));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += BNPVI_ROR(v, 1);
+  v += BNPVI_ROR(v, 2);
+  v += BNPVI_ROR(v, 4);
+  return v + BNPVI_ROR(v, 8);
+}
+
 // Everything a wave needs to know about the leaf side
 struct LeafOperands {
   const f16x8* a;        // packed alpha: [(T*S+s)*2+part][64 lanes] x 8 halfs (LDS or global)
@@ -99,10 +129,8 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
       amax = fmaxf(amax, fabsf(v[e]));
     }
   }
-  zz += __shfl_xor(zz, 16);
-  zz += __shfl_xor(zz, 32);
-  amax = fmaxf(amax, __shfl_xor(amax, 16));
-  amax = fmaxf(amax, __shfl_xor(amax, 32));
+  zz = cols4_sum(zz);
+  amax = cols4_max(amax);
   const int kz = scale_exponent_bits(__float_as_int(amax));
   const float sz = pow2f(kz);
   f16x8 bh[S], bl[S];
@@ -147,7 +175,8 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   }
   const float snmax = zz + lo_.aamax;
   unsigned pend = 0u;
-  if (__ballot(dmin < kRefineRel * snmax * snmax) != 0ull) {
+  if (__builtin_expect(__ballot(dmin < kRefineRel * snmax * snmax) != 0ull, 0)) {
+    asm volatile("" ::: "memory");        // nothing of the rare path is speculated above the branch
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       if (T < tiles_valid) {
@@ -349,8 +378,7 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
     m = fmaxf(fmaxf(m, lg[T][0]), lg[T][1]);
     m = fmaxf(fmaxf(m, lg[T][2]), lg[T][3]);
   }
-  m = fmaxf(m, __shfl_xor(m, 16));
-  m = fmaxf(m, __shfl_xor(m, 32));
+  m = cols4_max(m);
   f32x2 ss = {0.f, 0.f};
   const f32x2 m2 = {m, m};
 #pragma unroll
@@ -364,9 +392,7 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
       lg[T][2 * h + 1] = e[1];
     }
   }
-  float ssum = ss[0] + ss[1];
-  ssum += __shfl_xor(ssum, 16);
-  ssum += __shfl_xor(ssum, 32);
+  const float ssum = cols4_sum(ss[0] + ss[1]);
   // lanes past the last frame get phi = 0: nothing enters the statistics, nothing is stored
   const float inv = ok ? __builtin_amdgcn_rcpf(ssum) : 0.f;
   const f32x2 inv2 = {inv, inv};

@@ -20,33 +20,22 @@
 
 namespace bnpvi {
 
-constexpr int kRWaves = 8;            // waves per workgroup
+#ifndef BNPVI_ROWS_WAVES
+#define BNPVI_ROWS_WAVES 12
+#endif
+constexpr int kRWaves = BNPVI_ROWS_WAVES;   // waves per workgroup (3 per SIMD)
 constexpr int kRChunk = 4;            // 16-leaf tiles per online-softmax chunk (64 leaves)
-constexpr int kRStageW = 32;          // leaves staged per store round
-constexpr int kRStageLd = kRStageW + 4;   // staging row stride in floats (bank-conflict-free)
 
 template <int DP>
 struct RowsLds {
   static size_t bytes(int NTp, bool stats) {
     return (size_t)NTp * (DP / 32) * 2 * 64 * 16 + (size_t)kLT * NTp * 4 +
-           (stats ? (size_t)kLT * NTp * 8 : 0) + (size_t)kRWaves * kFT * kRStageLd * 4;
+           (stats ? (size_t)kLT * NTp * 8 : 0);
   }
 };
 
-// 16 lanes (one leaf column each, same lane>>4) -> all-reduce
-__device__ __forceinline__ float row16_max(float v) {
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) v = fmaxf(v, __shfl_xor(v, off));
-  return v;
-}
-__device__ __forceinline__ float row16_sum(float v) {
-#pragma unroll
-  for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
-  return v;
-}
-
 template <int DP, bool STATS>
-__global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
+__global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
     const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
     int NTp /* 16-leaf tiles, padded to a multiple of kRChunk */, const f16x8* __restrict__ apack,
     const float* __restrict__ aavec, const float* __restrict__ a32, const float* __restrict__ scal,
@@ -57,7 +46,6 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
   f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                    // [NTp*S*2*64]
   float* aa_lds = reinterpret_cast<float*>(a_lds + (size_t)NTp * S * 2 * 64);   // [16*NTp]
   float* st_lds = aa_lds + kLT * NTp;                                   // [16*NTp][2] (STATS)
-  float* stage_all = st_lds + (STATS ? 2 * kLT * NTp : 0);              // [waves][16][kRStageLd]
   const int tiles_valid = Lp / kLT;
 
   for (int e = threadIdx.x; e < NTp * S * 2 * 64; e += blockDim.x)
@@ -71,7 +59,6 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int c = lane & 15;
   const int kg = lane >> 4;
-  float* stage = stage_all + wave * (kFT * kRStageLd);
   const float inv_sa = scal[0];
   const float aamax = scal[2];
   const float c2 = -half_sz * kLog2e;
@@ -98,37 +85,44 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
         amax = fmaxf(amax, fabsf(v[e]));
       }
     }
-    zz += __shfl_xor(zz, 16);
-    zz += __shfl_xor(zz, 32);
-    amax = fmaxf(amax, __shfl_xor(amax, 16));
-    amax = fmaxf(amax, __shfl_xor(amax, 32));
+    zz = cols4_sum(zz);
+    amax = cols4_max(amax);
     const int kz = scale_exponent_bits(__float_as_int(amax));
     f16x8 zh[S], zl[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) split8(zA[s], zB[s], pow2f(kz), zh[s], zl[s]);
     if (tile + kRWaves < t1) load_ztile<DP>(Z, ldz, (tile + kRWaves) * kFT, N, lane, zA, zB);
 
-    // the lane's 4 frames (rows 4kg + r): ||z||^2, un-scaling factor, prior row, validity
+    // the lane's 4 frames (rows 4kg + r): ||z||^2, un-scaling factor, prior row, validity.
+    // Frames are handled in PAIRS (r, r+1) on the packed fp32 pipe.
     const float unscale = -2.f * pow2f(-kz) * inv_sa;
-    float zzr[4], unr[4], thr[4];
+    f32x2 zz2[2], un2[2], thr2[2];
     const float* prow[4];
     bool okr[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      zzr[r] = __shfl(zz, 4 * kg + r);
-      unr[r] = __shfl(unscale, 4 * kg + r);
-      const float sn = zzr[r] + aamax;
-      thr[r] = kRefineRel * sn * sn;
+      const float zr = __shfl(zz, 4 * kg + r);
+      zz2[r >> 1][r & 1] = zr;
+      un2[r >> 1][r & 1] = __shfl(unscale, 4 * kg + r);
+      const float sn = zr + aamax;
+      thr2[r >> 1][r & 1] = kRefineRel * sn * sn;
       const int64_t n = row0 + 4 * kg + r;
       okr[r] = n < N;
       prow[r] = prior + (int64_t)vid[okr[r] ? n : N - 1] * Lp + c;
     }
     const int64_t nlast = row0 + kFT - 1 < N ? row0 + kFT - 1 : N - 1;
     const bool onevid = vid[row0] == vid[nlast];       // wave-uniform: one prior row for the tile
+    const f32x2 c22 = {c2, c2};
+    const bool full = row0 + kFT <= N;                  // wave-uniform: no row of the tile is past N
+    unsigned voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) voff[r] = (unsigned)((4 * kg + r) * Lp + c);
 
-    // logits of one 64-leaf chunk for the lane's (leaf column, 4 frames): v[t][r] (log2 units)
-    // and d2[t][r]
-    auto chunk_logits = [&](int ch, f32x4 (&d2)[kRChunk], f32x4 (&v)[kRChunk]) {
+    // One 64-leaf chunk for the lane's (leaf column, 4 frames): squared distances d[t][pair] and
+    // log2-unit logits v[t][pair].  No clamp of d at zero: a negative d is below the
+    // cancellation bound, so it is replaced by the exact value on the rare path; padded leaves
+    // (prior -inf) go through |d|.
+    auto chunk_logits = [&](int ch, f32x2 (&d)[kRChunk][2], f32x2 (&v)[kRChunk][2]) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 acc[kRChunk];
 #pragma unroll
@@ -143,33 +137,49 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zh[s], ah, acc[t], 0, 0, 0);
         }
       }
-      float pr[kRChunk][4];
+#ifndef BNPVI_ROWS_NO_SCHED
+      // issue order: the first k-step's 8 operand reads, then every 3 MFMAs hide the next 2 reads
+      // (LDS latency overlaps matrix-pipe time instead of stalling in front of each MFMA)
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * kRChunk, 0);
+#pragma unroll
+      for (int g = 0; g < (S - 1) * kRChunk; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * kRChunk, 0);
+#endif
+      f32x2 pr[kRChunk][2];
 #pragma unroll
       for (int t = 0; t < kRChunk; ++t) {
         const int T = ch * kRChunk + t;
         const bool tv = T < tiles_valid;
         if (onevid) {
           const float p = tv ? prow[0][kLT * T] : -INFINITY;
-          pr[t][0] = pr[t][1] = pr[t][2] = pr[t][3] = p;
+          pr[t][0] = (f32x2){p, p};
+          pr[t][1] = (f32x2){p, p};
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pr[t][r] = tv ? prow[r][kLT * T] : -INFINITY;
+          for (int r = 0; r < 4; ++r) pr[t][r >> 1][r & 1] = tv ? prow[r][kLT * T] : -INFINITY;
         }
       }
-      float dmin[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+      f32x2 dmin[2] = {{INFINITY, INFINITY}, {INFINITY, INFINITY}};
 #pragma unroll
       for (int t = 0; t < kRChunk; ++t) {
         const float aa = aa_lds[kLT * (ch * kRChunk + t) + c];
+        const f32x2 aa2 = {aa, aa};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = fmaxf(fmaf(unr[r], acc[t][r], zzr[r] + aa), 0.f);
-          d2[t][r] = d;
-          dmin[r] = fminf(dmin[r], d);
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 a2 = {acc[t][2 * h], acc[t][2 * h + 1]};
+          d[t][h] = un2[h] * a2 + zz2[h] + aa2;
+          dmin[h][0] = fminf(dmin[h][0], d[t][h][0]);
+          dmin[h][1] = fminf(dmin[h][1], d[t][h][1]);
         }
       }
       // cancellation screen (see estep_kernels.h): rare exact recomputation by direct differences
-      const bool sus = (dmin[0] < thr[0]) | (dmin[1] < thr[1]) | (dmin[2] < thr[2]) | (dmin[3] < thr[3]);
-      if (__ballot(sus) != 0ull) {
+      const bool sus = (dmin[0][0] < thr2[0][0]) | (dmin[0][1] < thr2[0][1]) | (dmin[1][0] < thr2[1][0]) |
+                       (dmin[1][1] < thr2[1][1]);
+      if (__builtin_expect(__ballot(sus) != 0ull, 0)) {
+        asm volatile("" ::: "memory");      // nothing of the rare path is speculated above the branch
         unsigned pend = 0u;
 #pragma unroll
         for (int t = 0; t < kRChunk; ++t) {
@@ -177,8 +187,8 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
           const float aa = aa_lds[leaf];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float sn = zzr[r] + aa;
-            if (d2[t][r] < kRefineRel * sn * sn && leaf < L) pend |= 1u << (t * 4 + r);
+            const float sn = zz2[r >> 1][r & 1] + aa;
+            if (d[t][r >> 1][r & 1] < kRefineRel * sn * sn && leaf < L) pend |= 1u << (t * 4 + r);
           }
         }
         while (true) {
@@ -191,8 +201,8 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
           if (ns >= N) ns = N - 1;
           const int leaf = kLT * (ch * kRChunk + (idx >> 2)) + (src & 15);
           float p = 0.f;
-          for (int d = lane; d < DP; d += 64) {
-            const float df = Z[ns * ldz + d] - a32[(int64_t)leaf * DP + d];
+          for (int dd = lane; dd < DP; dd += 64) {
+            const float df = Z[ns * ldz + dd] - a32[(int64_t)leaf * DP + dd];
             p = fmaf(df, df, p);
           }
 #pragma unroll
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
             for (int t = 0; t < kRChunk; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                if (idx == t * 4 + r) d2[t][r] = p;
+                if (idx == t * 4 + r) d[t][r >> 1][r & 1] = p;
             pend &= ~(1u << idx);
           }
         }
@@ -210,95 +220,102 @@ __global__ __launch_bounds__(kRWaves * 64, 2) void estep_rows_kernel(
 #pragma unroll
       for (int t = 0; t < kRChunk; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[t][r] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[t][r]), pr[t][r]);
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 sq = {__builtin_amdgcn_sqrtf(__builtin_fabsf(d[t][h][0])),
+                            __builtin_amdgcn_sqrtf(__builtin_fabsf(d[t][h][1]))};
+          v[t][h] = c22 * sq + pr[t][h];
+        }
     };
 
     // ---- pass 1: online max / sum-exp per frame over the lane's leaf column
-    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 m2[2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
+    f32x2 ss2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int ch = 0; ch < nchunk; ++ch) {
-      f32x4 d2[kRChunk], v[kRChunk];
-      chunk_logits(ch, d2, v);
+      f32x2 d[kRChunk][2], v[kRChunk][2];
+      chunk_logits(ch, d, v);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float cm = v[0][r];
+      for (int h = 0; h < 2; ++h) {
+        f32x2 mn;
 #pragma unroll
-        for (int t = 1; t < kRChunk; ++t) cm = fmaxf(cm, v[t][r]);
-        const float mn = fmaxf(m[r], cm);
-        // a lane whose leaves so far are all padding keeps (m, sum) = (-inf, 0)
-        float acc = (mn == -INFINITY) ? 0.f : ssum[r] * __builtin_amdgcn_exp2f(m[r] - mn);
+        for (int q = 0; q < 2; ++q) {
+          float cm = fmaxf(fmaxf(v[0][h][q], v[1][h][q]), fmaxf(v[2][h][q], v[3][h][q]));
+          mn[q] = fmaxf(m2[h][q], cm);
+        }
+        // a lane whose leaves so far are all padding has mn = -inf: keep (m, sum) = (-inf, 0);
+        // exp2 of (-inf) - (finite) is 0, of (-inf) - (-inf) NaN -> shift by 0 instead
+        const f32x2 sh = {mn[0] == -INFINITY ? 0.f : mn[0], mn[1] == -INFINITY ? 0.f : mn[1]};
+        const f32x2 resc = m2[h] - sh;
+        f32x2 acc2 = ss2[h] * (f32x2){__builtin_amdgcn_exp2f(resc[0]), __builtin_amdgcn_exp2f(resc[1])};
 #pragma unroll
-        for (int t = 0; t < kRChunk; ++t) acc += (mn == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(v[t][r] - mn);
-        ssum[r] = acc;
-        m[r] = mn;
+        for (int t = 0; t < kRChunk; ++t) {
+          const f32x2 x = v[t][h] - sh;
+          acc2 += (f32x2){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+        }
+        ss2[h] = acc2;
+        m2[h] = mn;
       }
     }
     // combine the 16 leaf columns of each frame
-    float M[4], inv[4], lse2[4];
+    f32x2 M2[2], inv2[2], lse2[2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      M[r] = row16_max(m[r]);
-      const float sc = (m[r] == -INFINITY) ? 0.f : ssum[r] * __builtin_amdgcn_exp2f(m[r] - M[r]);
+      const float mr = m2[r >> 1][r & 1];
+      const float Mr = row16_max(mr);
+      const float sc = (mr == -INFINITY) ? 0.f : ss2[r >> 1][r & 1] * __builtin_amdgcn_exp2f(mr - Mr);
       const float tot = row16_sum(sc);
-      inv[r] = okr[r] ? __builtin_amdgcn_rcpf(tot) : 0.f;      // rows past N: phi = 0, not stored
-      lse2[r] = __builtin_amdgcn_logf(tot);                    // log2 of the sum
+      M2[r >> 1][r & 1] = Mr;
+      inv2[r >> 1][r & 1] = okr[r] ? __builtin_amdgcn_rcpf(tot) : 0.f;   // rows past N: phi = 0, not stored
+      lse2[r >> 1][r & 1] = __builtin_amdgcn_logf(tot);                  // log2 of the sum
     }
 
-    // ---- pass 2: recompute, normalise, accumulate statistics, store through the staging tile
+    // ---- pass 2: recompute, normalise, accumulate statistics, store
     for (int ch = 0; ch < nchunk; ++ch) {
-      f32x4 d2[kRChunk], v[kRChunk];
-      chunk_logits(ch, d2, v);
-      f32x4 pv[kRChunk];
+      f32x2 d[kRChunk][2], v[kRChunk][2];
+      chunk_logits(ch, d, v);
+      f32x2 pv[kRChunk][2];
 #pragma unroll
       for (int t = 0; t < kRChunk; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[t][r] = __builtin_amdgcn_exp2f(v[t][r] - M[r]) * inv[r];
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 x = v[t][h] - M2[h];
+          pv[t][h] = (f32x2){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} * inv2[h];
+        }
       if (STATS) {
 #pragma unroll
         for (int t = 0; t < kRChunk; ++t) {
           const int leaf = kLT * (ch * kRChunk + t) + c;
-          float a0 = (pv[t][0] + pv[t][1]) + (pv[t][2] + pv[t][3]);
-          float a2 = fmaf(pv[t][0], d2[t][0], fmaf(pv[t][1], d2[t][1], fmaf(pv[t][2], d2[t][2], pv[t][3] * d2[t][3])));
+          const f32x2 s0p = pv[t][0] + pv[t][1];
+          const f32x2 s2p = pv[t][0] * d[t][0] + pv[t][1] * d[t][1];
           // the 4 lane groups hold different frames of the same leaf
-          a0 += __shfl_xor(a0, 16);
-          a2 += __shfl_xor(a2, 16);
-          a0 += __shfl_xor(a0, 32);
-          a2 += __shfl_xor(a2, 32);
+          const float a0 = cols4_sum(s0p[0] + s0p[1]);
+          const float a2 = cols4_sum(s2p[0] + s2p[1]);
           if (kg == 0 && leaf < L) {
             atomicAdd(&st_lds[2 * leaf], a0);
             atomicAdd(&st_lds[2 * leaf + 1], a2);
           }
         }
       }
-      // staging: [frame row][32 leaves] -> 16 B per lane, 128-byte row segments
+      // direct stores: per instruction the wave writes 4 frame rows x 64 B (16 leaf lanes x 4 B);
+      // the other half of each 128-byte line follows with the next leaf tile.  Wave-uniform base
+      // (tile row, leaf tile) + a fixed 32-bit lane offset per frame row.
 #pragma unroll
-      for (int hf = 0; hf < kRChunk / 2; ++hf) {
-        const int T0 = ch * kRChunk + 2 * hf;
-        if (T0 < tiles_valid) {                      // Lp is a multiple of 32: both tiles or none
-          const int srow = lane >> 3, scol = 4 * (lane & 7);
+      for (int t = 0; t < kRChunk; ++t) {
+        const int T = ch * kRChunk + t;
+        if (T < tiles_valid) {
+          float* tb = phi + row0 * Lp + kLT * T;
+          float* lb = logphi ? logphi + row0 * Lp + kLT * T : nullptr;
+          if (full) {
 #pragma unroll
-          for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1 && logphi == nullptr) break;
+            for (int r = 0; r < 4; ++r) tb[voff[r]] = pv[t][r >> 1][r & 1];
+          } else {
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt)
+            for (int r = 0; r < 4; ++r)
+              if (okr[r]) tb[voff[r]] = pv[t][r >> 1][r & 1];
+          }
+          if (lb) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int t = 2 * hf + tt;
-                const float val = pass == 0 ? pv[t][r] : (v[t][r] - M[r] - lse2[r]) * kLn2;
-                stage[(4 * kg + r) * kRStageLd + kLT * tt + c] = val;
-              }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float* dst = (pass == 0 ? phi : logphi) + kLT * T0 + scol;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-              const int fr = srow + 8 * q;
-              const float4 o = *reinterpret_cast<const float4*>(&stage[fr * kRStageLd + scol]);
-              const int64_t n = row0 + fr;
-              if (n < N) *reinterpret_cast<float4*>(dst + n * Lp) = o;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 4; ++r)
+              if (okr[r]) lb[voff[r]] = (v[t][r >> 1][r & 1] - M2[r >> 1][r & 1] - lse2[r >> 1][r & 1]) * kLn2;
           }
         }
       }
