@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("BNPVI_LIB") or os.path.join(_HERE, "libbnpvi.so")   #
 OK = 0
 ESTEP_SOFT = 0
 ESTEP_HARD = 1
+ESTEP_OPERANDS_READY = 0x100
 
 
 class BnpviError(RuntimeError):
@@ -61,6 +62,7 @@ EXPORTS = {
     "bnpvi_gamma_remap": (_i, [_p, _p, _i, _p, _i, _i, _p, _d, _p]),
     "bnpvi_prior_table": (_i, [_p, _p, _p, _p, _i, _d, _p, _p, _p, _p]),
     "bnpvi_gamma_prior": (_i, [_p, _p, _p, _p, _i, _d, _d, _p, _p, _p]),
+    "bnpvi_params_prior": (_i, [_p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p, _i, _d, _p, _p, _p]),
     "bnpvi_estep": (_i, [_p, _p, _p, _i, _p, _i64, _i, _p, _p, _d, _i, _p, _p, _p, _p, _p]),
     "bnpvi_kmeans_pass": (_i, [_p, _p, _i, _i64, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "bnpvi_remap_columns": (_i, [_p, _p, _i, _p, _i, _i64, _i, _p, _p, _p]),

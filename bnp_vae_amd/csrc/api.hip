@@ -332,6 +332,18 @@ int bnpvi_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass
   return launch_gamma_prior(ctx, tree, mass, sigma, V, gamma_hyper, sZ, gamma, prior, (hipStream_t)stream);
 }
 
+int bnpvi_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* stats, int W, int D, double sB,
+                       double sZ, const double* alpha0, double* alpha, double* sigma, double* mass, int V,
+                       double gamma_hyper, double* gamma, float* prior, void* stream) {
+  BNPVI_REQUIRE(ctx && tree && stats && alpha && sigma && mass && gamma && prior,
+                "bnpvi_params_prior: NULL argument");
+  BNPVI_REQUIRE(D >= 1 && bnpvi_padded_dim(D) > 0 && W >= 1 + D && V >= 1,
+                "bnpvi_params_prior: D=%d stats_width=%d V=%d", D, W, V);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_params_prior(ctx, tree, stats, W, D, sB, sZ, alpha0, alpha, sigma, mass, V, gamma_hyper, gamma,
+                             prior, (hipStream_t)stream);
+}
+
 int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,
                 const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
                 double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
@@ -339,8 +351,9 @@ int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,
   int rc = check_common("bnpvi_estep", ctx, N, D, ldz);
   if (rc) return rc;
   BNPVI_REQUIRE(tree && Z && alpha && phi, "bnpvi_estep: NULL argument");
-  BNPVI_REQUIRE(mode == BNPVI_ESTEP_SOFT || mode == BNPVI_ESTEP_HARD, "bnpvi_estep: mode=%d", mode);
-  BNPVI_REQUIRE(mode == BNPVI_ESTEP_HARD || (prior && vid),
+  const int base_mode = mode & ~BNPVI_ESTEP_OPERANDS_READY;
+  BNPVI_REQUIRE(base_mode == BNPVI_ESTEP_SOFT || base_mode == BNPVI_ESTEP_HARD, "bnpvi_estep: mode=%d", mode);
+  BNPVI_REQUIRE(base_mode == BNPVI_ESTEP_HARD || (prior && vid),
                 "bnpvi_estep: soft mode needs prior and vid");
   return launch_estep(ctx, tree, Z, ldz, vid, N, D, alpha, prior, sZ, mode, phi, logphi, assign,
                       estats, (hipStream_t)stream);

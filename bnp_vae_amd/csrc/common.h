@@ -80,6 +80,12 @@ struct bnpvi_ctx {
   bnpvi::Scratch cols;       // column maps of remap_columns
   bnpvi::KernelTimer timer[2];   // BNPVI_PROF_ESTEP / BNPVI_PROF_MSTEP main kernels
   bool profiling = false;
+  // leaf operands packed ahead of the E-step by bnpvi_params_prior (one use)
+  const bnpvi_tree* ops_tree = nullptr;
+  const double* ops_alpha = nullptr;
+  int ops_D = 0;
+  // per-video mass buffer that bnpvi_params_prior left zeroed (bnpvi_leaf_stats skips its memset)
+  const double* mass_clean = nullptr;
 };
 
 struct bnpvi_tree {
@@ -116,6 +122,11 @@ int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
 // gamma-step + prior table in one launch (per-video work, no collective in between)
 int launch_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass, const double* sigma, int V,
                        double gamma_hyper, double sZ, double* gamma, float* prior, hipStream_t s);
+
+// node parameters + gamma + prior table (+ leaf operands for the next E-step) ; small trees: one launch
+int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D, double sB,
+                        double sZ, const double* alpha0, double* alpha, double* sigma, double* mass, int V,
+                        double gamma_hyper, double* gamma, float* prior, hipStream_t s);
 
 int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
                  const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,

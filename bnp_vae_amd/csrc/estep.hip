@@ -69,6 +69,14 @@ __global__ void pack_leaves_kernel(const float* __restrict__ a32, int DP, int Lp
   apack[u] = out;
 }
 
+// Small trees: rows, norms, scale and packed fragments in one workgroup (leaf_operands_block,
+// estep_kernels.h); also the tail of the fused mid-step kernel (tree_kernels.hip).
+__global__ __launch_bounds__(1024) void leaf_operands_small_kernel(
+    const double* __restrict__ alpha, int D, int DP, const int32_t* __restrict__ node_of_leaf, int L, int Lp,
+    float* a32, float* __restrict__ aavec, f16x8* __restrict__ apack, float* __restrict__ scal) {
+  leaf_operands_block(alpha, D, DP, node_of_leaf, L, Lp, a32, aavec, apack, scal);
+}
+
 // ------------------------------------------------------------------------------------------
 // Streamed regime, pass B: combine the partials of a frame, normalise its row in place,
 // accumulate S0' / S2.  One wave per row at a time, lanes stride the row in float4.
@@ -222,11 +230,7 @@ template <> int estep_dispatch<64>(const EstepArgs&);
 template <> int estep_dispatch<128>(const EstepArgs&);
 template <> int estep_dispatch<256>(const EstepArgs&);
 
-int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
-                 const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
-                 double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
-                 hipStream_t s) {
-  const int DP = bnpvi_padded_dim(D);
+int leaf_workspace(bnpvi_ctx* ctx, const bnpvi_tree* t, int DP, LeafWorkspace* w) {
   // the streamed regime reads whole chunks of the packed operands: pad to a chunk of tiles
   const int LpPack = round_up(t->Lp, kLT * kStreamNT);
   // workspace: [apack f16 hi/lo: LpPack*DP*4 B][a32: LpPack*DP*4 B][aa: LpPack*4 B][scal 16 B]
@@ -234,16 +238,42 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
   int rc = ctx->pack.ensure(2 * img + (size_t)LpPack * 4 + 16);
   if (rc) return rc;
   char* base = (char*)ctx->pack.ptr;
-  f16x8* apack = (f16x8*)base;
-  float* a32 = (float*)(base + img);
-  float* aavec = (float*)(base + 2 * img);
-  float* scal = aavec + LpPack;          // [0] = 2^-ka, [1] = bits of max|alpha|, [2] = max ||alpha||^2
+  w->LpPack = LpPack;
+  w->apack = (f16x8*)base;
+  w->a32 = (float*)(base + img);
+  w->aavec = (float*)(base + 2 * img);
+  w->scal = w->aavec + LpPack;      // [0] = 2^-ka, [1] = bits of max|alpha|, [2] = max ||alpha||^2
+  return BNPVI_OK;
+}
+
+int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
+                 const int32_t* vid, int64_t N, int D, const double* alpha, const float* prior,
+                 double sZ, int mode, float* phi, float* logphi, int32_t* assign, double* estats,
+                 hipStream_t s) {
+  const int DP = bnpvi_padded_dim(D);
+  LeafWorkspace w;
+  int rc = leaf_workspace(ctx, t, DP, &w);
+  if (rc) return rc;
+  const int LpPack = w.LpPack;
+  f16x8* apack = w.apack;
+  float *a32 = w.a32, *aavec = w.aavec, *scal = w.scal;
   int* amax_bits = (int*)(scal + 1);
-  BNPVI_HIP(hipMemsetAsync(amax_bits, 0, 2 * sizeof(int), s));
-  hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 4)), dim3(256), 0, s, alpha, D, DP,
-                     t->d_node_of_leaf, t->L, LpPack, a32, aavec, amax_bits);
-  BNPVI_LAUNCH_CHECK();
-  {
+  const bool ready = (mode & BNPVI_ESTEP_OPERANDS_READY) && ctx->ops_tree == t && ctx->ops_D == D &&
+                     ctx->ops_alpha == alpha;
+  mode &= ~BNPVI_ESTEP_OPERANDS_READY;
+  ctx->ops_tree = nullptr;                      // one use: alpha may change before the next call
+  if (ready) {
+    // packed by bnpvi_params_prior from this very alpha buffer
+  } else
+  if ((int64_t)LpPack * DP <= 64 * 1024) {
+    hipLaunchKernelGGL(leaf_operands_small_kernel, dim3(1), dim3(1024), 0, s, alpha, D, DP, t->d_node_of_leaf,
+                       t->L, LpPack, a32, aavec, apack, scal);
+    BNPVI_LAUNCH_CHECK();
+  } else {
+    BNPVI_HIP(hipMemsetAsync(amax_bits, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(leaf_rows_kernel, dim3((unsigned)ceil_div(LpPack, 4)), dim3(256), 0, s, alpha, D, DP,
+                       t->d_node_of_leaf, t->L, LpPack, a32, aavec, amax_bits);
+    BNPVI_LAUNCH_CHECK();
     const int64_t units = (int64_t)(LpPack / kLT) * (DP / 32) * 2 * 64;
     hipLaunchKernelGGL(pack_leaves_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, s, a32, DP,
                        LpPack, amax_bits, apack, scal);

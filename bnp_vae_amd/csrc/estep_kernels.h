@@ -641,6 +641,81 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Leaf operands of a small tree by ONE workgroup: fp32 rows, ||alpha||^2, max|alpha| (block
+// reduction), barrier, then the scaled hi/lo f16 fragments in MFMA operand order (layout in
+// estep.hip).  a32 is re-read after the barrier by other threads of the same workgroup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void leaf_operands_block(
+    const double* __restrict__ alpha, int D, int DP, const int32_t* __restrict__ node_of_leaf, int L, int Lp,
+    float* a32, float* __restrict__ aavec, f16x8* __restrict__ apack, float* __restrict__ scal) {
+  __shared__ float red[2][16];          // up to 16 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  float amax = 0.f, aamax = 0.f;
+  for (int leaf = wave; leaf < Lp; leaf += nw) {
+    const double* a = leaf < L ? alpha + (int64_t)node_of_leaf[leaf] * D : nullptr;
+    double aa = 0.0;
+    for (int d = lane; d < DP; d += 64) {
+      const float f = (a && d < D) ? (float)a[d] : 0.f;
+      a32[(int64_t)leaf * DP + d] = f;
+      aa += (double)f * (double)f;
+      amax = fmaxf(amax, fabsf(f));
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) aa += __shfl_xor(aa, off);
+    if (lane == 0) aavec[leaf] = (float)aa;
+    aamax = fmaxf(aamax, (float)aa);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if (lane == 0) {
+    red[0][wave] = amax;
+    red[1][wave] = aamax;
+  }
+  __syncthreads();                                 // also orders the a32 rows for the readers below
+  amax = 0.f;
+  aamax = 0.f;
+  for (int w = 0; w < nw; ++w) {
+    amax = fmaxf(amax, red[0][w]);
+    aamax = fmaxf(aamax, red[1][w]);
+  }
+  const int ka = scale_exponent_bits(__float_as_int(amax));
+  if (threadIdx.x == 0) {
+    scal[0] = pow2f(-ka);
+    scal[1] = amax;
+    scal[2] = aamax;
+  }
+  const int S = DP / 32;
+  const float sa = pow2f(ka);
+  for (int u = threadIdx.x; u < (Lp / kLT) * S * 2 * 64; u += blockDim.x) {
+    const int ln = u & 63;
+    const int part = (u >> 6) & 1;
+    const int ts = u >> 7;
+    const int s = ts % S, T = ts / S;
+    const int leaf = kLT * T + (ln & 15);
+    const int kg = ln >> 4;
+    f16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int dim = 32 * s + 16 * (e >> 2) + 4 * kg + (e & 3);
+      const float v = a32[(int64_t)leaf * DP + dim] * sa;
+      const _Float16 h = (_Float16)v;
+      out[e] = part == 0 ? h : (_Float16)(v - (float)h);
+    }
+    apack[u] = out;
+  }
+}
+
+
+struct LeafWorkspace {
+  int LpPack;
+  f16x8* apack;
+  float* a32;
+  float* aavec;
+  float* scal;
+};
+int leaf_workspace(bnpvi_ctx* ctx, const bnpvi_tree* t, int DP, LeafWorkspace* w);
+
 // per-DP launchers (estep_inst.hip, compiled once per DP)
 struct EstepArgs {
   bnpvi_ctx* ctx;

@@ -11,8 +11,10 @@
 //   * the softmax runs over lanes and leaf tiles: per frame an ONLINE max / sum-exp over chunks
 //     of 64 leaves (pass 1), combined over the 16 leaf lanes once per frame tile;
 //   * pass 2 recomputes the chunk's logits (MFMAs on the f16 pipe are cheap) and writes
-//     phi = exp2(logit - max) / sum through a wave-private LDS staging tile, so global stores
-//     are whole 128-byte row segments, 16 B per lane.
+//     phi = exp2(logit - max) / sum straight from the accumulator layout: one store instruction
+//     covers 4 frame rows x 64 B, the other half of each 128-byte line follows with the next
+//     leaf tile (an LDS staging tile for 16-byte stores measured slower: it serialises the wave
+//     on LDS round trips and caps the workgroup at 8 waves).
 // HBM traffic is the algorithmic minimum: Z read once, phi written once (no logits round trip).
 #pragma once
 

@@ -369,7 +369,10 @@ int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi,
                       double* stats, double* mass, hipStream_t s) {
   const int Dp = bnpvi_padded_dim(D);
   const int W = 1 + D * (want_q ? 2 : 1);
-  if (mass) BNPVI_HIP(hipMemsetAsync(mass, 0, (size_t)V * L * sizeof(double), s));
+  // the mass rows are accumulated with atomics: they must start at zero (bnpvi_params_prior leaves
+  // the buffer it consumed zeroed, so the steady-state iteration needs no memset)
+  if (mass && ctx->mass_clean != mass) BNPVI_HIP(hipMemsetAsync(mass, 0, (size_t)V * L * sizeof(double), s));
+  if (mass) ctx->mass_clean = nullptr;
   if (N == 0) {
     BNPVI_HIP(hipMemsetAsync(stats, 0, (size_t)L * W * sizeof(double), s));
     return BNPVI_OK;

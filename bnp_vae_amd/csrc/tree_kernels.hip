@@ -9,6 +9,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "estep_kernels.h"
 
 namespace bnpvi {
 
@@ -51,7 +52,7 @@ __global__ void node_params_level_kernel(const int32_t* __restrict__ level_nodes
 
 // Small trees: every level in ONE launch by one workgroup (a level's writes are visible to the
 // next level's reads through the workgroup barrier; alpha is not __restrict__ here).
-__global__ __launch_bounds__(1024) void node_params_tree_kernel(
+__device__ __forceinline__ void node_params_tree_block(
     const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_ptr, int nlevels,
     const int32_t* __restrict__ parent, const int32_t* __restrict__ leaf_of_node,
     const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
@@ -84,6 +85,16 @@ __global__ __launch_bounds__(1024) void node_params_tree_kernel(
     }
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(1024) void node_params_tree_kernel(
+    const int32_t* __restrict__ level_nodes, const int32_t* __restrict__ level_ptr, int nlevels,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ leaf_of_node,
+    const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
+    const double* __restrict__ stats, int W, int D, double sB, double sZ,
+    const double* __restrict__ alpha0, double* alpha, double* __restrict__ sigma) {
+  node_params_tree_block(level_nodes, level_ptr, nlevels, parent, leaf_of_node, child_ptr, child_idx, stats, W,
+                         D, sB, sZ, alpha0, alpha, sigma);
 }
 
 int launch_node_params(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D,
@@ -306,24 +317,22 @@ __device__ __forceinline__ void wave_inclusive_scan(double* a, int n, int lane) 
   wave_sync_lds();
 }
 
-template <bool DO_GAMMA, bool DO_PRIOR>
-__global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
-    const double* __restrict__ mass, double* gamma, const double* __restrict__ sigma,
-    const int32_t* __restrict__ parent, const int32_t* __restrict__ node_of_leaf,
-    const int32_t* __restrict__ leaf_lo, const int32_t* __restrict__ leaf_hi, int V, int K, int L, int Lp,
+// One video by one wave.  leaf_sigma == nullptr: the leaf precisions come straight from the
+// statistics (sigma_l = sB + sZ*S0_l, src/var_inf.py:268-272) -- used when the node-parameter
+// update runs concurrently in the same launch.  ZERO_MASS: the mass row is zeroed once read.
+template <bool DO_GAMMA, bool DO_PRIOR, bool ZERO_MASS>
+__device__ __forceinline__ void stick_wave_video(
+    int v, int lane, double* Pm, double* e0, double* P, double* mass_rw, const double* __restrict__ mass,
+    double* gamma, const double* __restrict__ leaf_sigma, const double* __restrict__ stats, int W, double sB,
+    double sZ, const int32_t* __restrict__ parent, const int32_t* __restrict__ node_of_leaf,
+    const int32_t* __restrict__ leaf_lo, const int32_t* __restrict__ leaf_hi, int K, int L, int Lp,
     double gamma_hyper, double half_sz, float* __restrict__ prior, double* __restrict__ on_out,
     double* __restrict__ before_out) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  double* Pm = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (L + 2 * K);
-  double* e0 = Pm + L;
-  double* P = e0 + K;
-  const int v = blockIdx.x * kStickWaves + wave;
-  if (v >= V) return;
-
   if (DO_GAMMA) {
-    for (int l = lane; l < L; l += 64) Pm[l] = mass[(int64_t)v * L + l];
+    for (int l = lane; l < L; l += 64) {
+      Pm[l] = mass[(int64_t)v * L + l];
+      if (ZERO_MASS) mass_rw[(int64_t)v * L + l] = 0.0;
+    }
     wave_sync_lds();
     wave_inclusive_scan(Pm, L, lane);
   }
@@ -373,7 +382,8 @@ __global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
         }
       }
       const double before = (k > 0 ? P[k - 1] : 0.0) - anc;
-      const double val = on + before - half_sz / sigma[k];
+      const double sig = leaf_sigma ? leaf_sigma[k] : sB + sZ * stats[(int64_t)l * W];
+      const double val = on + before - half_sz / sig;
       if (pass == 0) {
         best = fmax(best, val);
       } else {
@@ -387,6 +397,114 @@ __global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
       for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
     }
   }
+}
+
+template <bool DO_GAMMA, bool DO_PRIOR>
+__global__ __launch_bounds__(kStickWaves * 64) void stick_wave_kernel(
+    const double* __restrict__ mass, double* gamma, const double* __restrict__ sigma,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ node_of_leaf,
+    const int32_t* __restrict__ leaf_lo, const int32_t* __restrict__ leaf_hi, int V, int K, int L, int Lp,
+    double gamma_hyper, double half_sz, float* __restrict__ prior, double* __restrict__ on_out,
+    double* __restrict__ before_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* Pm = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (L + 2 * K);
+  const int v = blockIdx.x * kStickWaves + wave;
+  if (v >= V) return;
+  stick_wave_video<DO_GAMMA, DO_PRIOR, false>(v, lane, Pm, Pm + L, Pm + L + K, nullptr, mass, gamma, sigma,
+                                              nullptr, 0, 0.0, 0.0, parent, node_of_leaf, leaf_lo, leaf_hi, K,
+                                              L, Lp, gamma_hyper, half_sz, prior, on_out, before_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Small trees: the whole middle of an iteration in ONE launch.  Workgroup 0 updates the node
+// parameters (all levels) and then packs the leaf operands of the coming E-step from the new
+// alpha; every other workgroup runs the stick chain (gamma + prior table) for 16 videos, one
+// per wave.  The two parts are independent (the prior's 1/sigma_l term is taken from the
+// statistics), so no workgroup waits for another.
+// ------------------------------------------------------------------------------------------
+constexpr int kMidWaves = 16;
+
+struct MidArgs {
+  // tree
+  const int32_t *level_nodes, *level_ptr, *parent, *leaf_of_node, *node_of_leaf, *child_ptr, *child_idx,
+      *leaf_lo, *leaf_hi;
+  int nlevels, K, L, Lp;
+  // node parameters
+  const double* stats;
+  int W, D;
+  double sB, sZ;
+  const double* alpha0;
+  double* alpha;
+  double* sigma;
+  // stick chain
+  double* mass;
+  int V;
+  double gamma_hyper;
+  double* gamma;
+  float* prior;
+  // leaf operands
+  int DP, LpPack;
+  float* a32;
+  float* aavec;
+  f16x8* apack;
+  float* scal;
+};
+
+__global__ __launch_bounds__(kMidWaves * 64) void midstep_small_kernel(MidArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x == 0) {
+    node_params_tree_block(a.level_nodes, a.level_ptr, a.nlevels, a.parent, a.leaf_of_node, a.child_ptr,
+                           a.child_idx, a.stats, a.W, a.D, a.sB, a.sZ, a.alpha0, a.alpha, a.sigma);
+    leaf_operands_block(a.alpha, a.D, a.DP, a.node_of_leaf, a.L, a.LpPack, a.a32, a.aavec, a.apack, a.scal);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  double* Pm = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (a.L + 2 * a.K);
+  const int v = (blockIdx.x - 1) * kMidWaves + wave;
+  if (v >= a.V) return;
+  stick_wave_video<true, true, true>(v, lane, Pm, Pm + a.L, Pm + a.L + a.K, a.mass, a.mass, a.gamma, nullptr,
+                                     a.stats, a.W, a.sB, a.sZ, a.parent, a.node_of_leaf, a.leaf_lo, a.leaf_hi,
+                                     a.K, a.L, a.Lp, a.gamma_hyper, 0.5 * a.sZ, a.prior, nullptr, nullptr);
+}
+
+int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats, int W, int D, double sB,
+                        double sZ, const double* alpha0, double* alpha, double* sigma, double* mass, int V,
+                        double gamma_hyper, double* gamma, float* prior, hipStream_t s) {
+  const int DP = bnpvi_padded_dim(D);
+  const size_t lds = (size_t)kMidWaves * (t->L + 2 * t->K) * sizeof(double);
+  const bool small = (int64_t)t->K * D <= 64 * 1024 && lds <= 64 * 1024 &&
+                     (int64_t)round_up(t->Lp, kLT * kStreamNT) * DP <= 64 * 1024;
+  ctx->ops_tree = nullptr;
+  if (!small) {
+    int rc = launch_node_params(ctx, t, stats, W, D, sB, sZ, alpha0, alpha, sigma, s);
+    if (rc) return rc;
+    return launch_gamma_prior(ctx, t, mass, sigma, V, gamma_hyper, sZ, gamma, prior, s);
+  }
+  LeafWorkspace w;
+  int rc = leaf_workspace(ctx, t, DP, &w);
+  if (rc) return rc;
+  MidArgs a;
+  a.level_nodes = t->d_level_nodes; a.level_ptr = t->d_level_ptr; a.parent = t->d_parent;
+  a.leaf_of_node = t->d_leaf_of_node; a.node_of_leaf = t->d_node_of_leaf; a.child_ptr = t->d_child_ptr;
+  a.child_idx = t->d_child_idx; a.leaf_lo = t->d_leaf_lo; a.leaf_hi = t->d_leaf_hi;
+  a.nlevels = t->nlevels; a.K = t->K; a.L = t->L; a.Lp = t->Lp;
+  a.stats = stats; a.W = W; a.D = D; a.sB = sB; a.sZ = sZ; a.alpha0 = alpha0; a.alpha = alpha; a.sigma = sigma;
+  a.mass = mass; a.V = V; a.gamma_hyper = gamma_hyper; a.gamma = gamma; a.prior = prior;
+  a.DP = DP; a.LpPack = w.LpPack; a.a32 = w.a32; a.aavec = w.aavec; a.apack = w.apack; a.scal = w.scal;
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)midstep_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(midstep_small_kernel, dim3(1 + (unsigned)ceil_div(V, kMidWaves)), dim3(kMidWaves * 64), lds,
+                     s, a);
+  BNPVI_LAUNCH_CHECK();
+  ctx->ops_tree = t;
+  ctx->ops_alpha = alpha;
+  ctx->ops_D = D;
+  ctx->mass_clean = mass;
+  return BNPVI_OK;
 }
 
 template <bool DO_GAMMA, bool DO_PRIOR>
@@ -632,40 +750,42 @@ int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out,
 }
 
 // ------------------------------------------------------------------------------------------
-// Fixed-order reduction of per-workgroup fp64 slabs: 32 outputs x 8 slab groups per block.
+// Fixed-order reduction of per-workgroup fp64 slabs: 32 outputs x 32 slab groups per block.
+// Group g sums slabs g, g+32, ... in ascending order, the 32 group sums are combined in order
+// (fixed summation tree => bit-reproducible).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const double* __restrict__ slab, int nslab,
-                                                          int64_t elems, double* __restrict__ out) {
-  __shared__ double sh[8][32];
+__global__ __launch_bounds__(1024) void slab_reduce_kernel(const double* __restrict__ slab, int nslab,
+                                                           int64_t elems, double* __restrict__ out) {
+  __shared__ double sh[32][33];
   const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
   const int64_t e = (int64_t)blockIdx.x * 32 + lane;
   double acc = 0.0;
   if (e < elems) {
     int g = grp;
-    for (; g + 24 < nslab; g += 32) {     // 4 independent loads in flight per thread
+    for (; g + 96 < nslab; g += 128) {     // 4 independent loads in flight per thread
       const double a0 = slab[(int64_t)g * elems + e];
-      const double a1 = slab[(int64_t)(g + 8) * elems + e];
-      const double a2 = slab[(int64_t)(g + 16) * elems + e];
-      const double a3 = slab[(int64_t)(g + 24) * elems + e];
+      const double a1 = slab[(int64_t)(g + 32) * elems + e];
+      const double a2 = slab[(int64_t)(g + 64) * elems + e];
+      const double a3 = slab[(int64_t)(g + 96) * elems + e];
       acc += a0;
       acc += a1;
       acc += a2;
       acc += a3;
     }
-    for (; g < nslab; g += 8) acc += slab[(int64_t)g * elems + e];
+    for (; g < nslab; g += 32) acc += slab[(int64_t)g * elems + e];
   }
   sh[grp][lane] = acc;
   __syncthreads();
   if (grp == 0 && e < elems) {
     double t = sh[0][lane];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += sh[k][lane];
+    for (int k = 1; k < 32; ++k) t += sh[k][lane];
     out[e] = t;
   }
 }
 
 int launch_slab_reduce(const double* slab, int nslab, int64_t elems, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(256), 0, s, slab,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(1024), 0, s, slab,
                      nslab, elems, out);
   BNPVI_LAUNCH_CHECK();
   return BNPVI_OK;

@@ -222,7 +222,8 @@ class DeviceVI(object):
                                     self.GAMMA, self.sZ, _ptr(self.gamma), _ptr(self.prior),
                                     self._stream()), "bnpvi_gamma_prior")
 
-    def estep(self, mode=_lib.ESTEP_SOFT, want_logphi=False, want_assign=False, want_stats=True):
+    def estep(self, mode=_lib.ESTEP_SOFT, want_logphi=False, want_assign=False, want_stats=True,
+              operands_ready=False):
         """src/var_inf.py:313-357, 383-393; HARD = one-hot nearest leaf (:126-132)."""
         Lp, L = self.tree.Lp, self.tree.L
         if self.phi is None or tuple(self.phi.shape) != (self.N, Lp):
@@ -234,7 +235,8 @@ class DeviceVI(object):
         check(lib.bnpvi_estep(self.ctx, self.tree.handle, _ptr(self.Z), self.Dp, _ptr(self.vid),
                               self.N, self.D, _ptr(self.alpha),
                               _ptr(self.prior if mode == _lib.ESTEP_SOFT else None), self.sZ,
-                              int(mode), _ptr(self.phi), _ptr(logphi), _ptr(assign),
+                              int(mode) | (_lib.ESTEP_OPERANDS_READY if operands_ready else 0),
+                              _ptr(self.phi), _ptr(logphi), _ptr(assign),
                               _ptr(self.estats if want_stats else None), self._stream()),
               "bnpvi_estep")
         return logphi, assign
@@ -242,13 +244,25 @@ class DeviceVI(object):
     def allreduce_estats(self):
         vdist.allreduce_sum_(self.estats, self.group)
 
+    def params_prior(self):
+        """node parameters + gamma-step + prior table (+ leaf operands) in one call."""
+        K, Lp = self.tree.K, self.tree.Lp
+        if self.gamma is None or tuple(self.gamma.shape) != (self.V, K, 2):
+            self.gamma = self._empty((self.V, K, 2), torch.float64)
+        if self.prior is None or tuple(self.prior.shape) != (self.V, Lp):
+            self.prior = self._empty((self.V, Lp), torch.float32)
+        check(lib.bnpvi_params_prior(self.ctx, self.tree.handle, _ptr(self.stats), int(self.stats.shape[1]),
+                                     self.D, self.sB, self.sZ, _ptr(self.alpha0), _ptr(self.alpha),
+                                     _ptr(self.sigma), _ptr(self.mass), self.V, self.GAMMA, _ptr(self.gamma),
+                                     _ptr(self.prior), self._stream()), "bnpvi_params_prior")
+
     def iteration(self, want_estats=True):
-        """One VI iteration: M-step -> gamma-step -> prior table -> E-step (var_inf.py:135-137)."""
+        """One VI iteration: M-step -> gamma-step -> prior table -> E-step (var_inf.py:135-137):
+        statistics pass, the single all-reduce, one mid-step call, E-step."""
         self.leaf_stats(want_q=False, want_mass=True)
         self.allreduce_stats()
-        self.node_params()
-        self.gamma_prior()
-        self.estep(want_stats=want_estats)
+        self.params_prior()
+        self.estep(want_stats=want_estats, operands_ready=True)
 
     # ------------------------------------------------------------------ split / merge support
     def kmeans_seed(self, col, num_centres):

@@ -46,8 +46,11 @@ enum {
 /* E-step modes */
 enum {
   BNPVI_ESTEP_SOFT = 0,   /* softmax responsibilities, src/var_inf.py:313-357,383-393 */
-  BNPVI_ESTEP_HARD = 1    /* one-hot nearest leaf, src/var_inf.py:126-132 (first-call init);
+  BNPVI_ESTEP_HARD = 1,   /* one-hot nearest leaf, src/var_inf.py:126-132 (first-call init);
                              same rule as compute_acc_frame_avg_dynamic.py:49-52 */
+  BNPVI_ESTEP_OPERANDS_READY = 0x100  /* OR-ed into the mode: the leaf operands of THIS alpha_dev
+                             were prepared by the preceding bnpvi_params_prior (ignored, and
+                             the operands rebuilt, when that is not the case) */
 };
 
 typedef struct bnpvi_ctx bnpvi_ctx;     /* per-device workspace (partial-sum slabs, scratch) */
@@ -128,6 +131,18 @@ int bnpvi_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* gamm
 int bnpvi_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass_dev,
                       const double* sigma_dev, int V, double gamma_hyper, double sigma_z_sqrinv,
                       double* gamma_dev, float* prior_dev, void* stream);
+
+/* ---- middle of one iteration in one call: src/var_inf.py:265-297 then :395-416, :359-381 --
+ * bnpvi_node_params + bnpvi_gamma_update + bnpvi_prior_table with the same results.  For small
+ * trees all of it is ONE kernel launch, which also prepares the leaf operands of the coming
+ * E-step (pass BNPVI_ESTEP_OPERANDS_READY to bnpvi_estep with the same alpha_dev).
+ * mass_dev is CONSUMED: it is zeroed once read, which is the state bnpvi_leaf_stats needs it
+ * in (its memset is then skipped). */
+int bnpvi_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* stats_dev,
+                       int stats_width, int D, double sigma_b_sqrinv, double sigma_z_sqrinv,
+                       const double* alpha0_dev, double* alpha_dev, double* sigma_dev,
+                       double* mass_dev, int V, double gamma_hyper, double* gamma_dev,
+                       float* prior_dev, void* stream);
 
 /* ---- E-step: src/var_inf.py:313-357,383-393 ---------------------------------------------
  * logit[n,l] = prior[vid[n],l] - 0.5*sZ*||z_n - alpha_l||_2   (UN-squared norm)

@@ -244,6 +244,39 @@ def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
     np.testing.assert_allclose(snapshot(vi)['phi'], pp, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("bf,levels", [(8, 2), (8, 3)])
+def test_fused_iteration_matches_separate_calls(bf, levels):
+    """DeviceVI.iteration (one mid-step call: node parameters + gamma + prior table + leaf
+    operands, small trees in ONE launch) against the same iteration made of the separate entry
+    points, and a second iteration on top (the mass buffer it leaves zeroed, operand reuse)."""
+    import torch
+    N, D = 5000, 64
+    ora, vi, Z = _regular_case(N, D, bf, levels, [256], seed=21)
+    for leaf, col in zip(vi._dfs_leaves(), snapshot(ora)['phi'].T):
+        leaf.phi = col.reshape(-1, 1)
+    vi._load_latents(Z); vi._sync_phi(); vi._sync_gamma()
+    dev = vi._dev
+    state = [t.clone() for t in (dev.phi, dev.alpha, dev.sigma, dev.gamma)]
+    outs = []
+    for fused in (False, True):
+        dev.phi, dev.alpha, dev.sigma, dev.gamma = [t.clone() for t in state]
+        for _ in range(2):
+            if fused:
+                dev.iteration(want_estats=True)
+            else:
+                dev.leaf_stats(want_q=False, want_mass=True)
+                dev.node_params()
+                dev.gamma_update()
+                dev.prior_table()
+                dev.estep(want_stats=True)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (dev.phi, dev.alpha, dev.sigma, dev.gamma, dev.prior, dev.estats)])
+    for a, b, name in zip(outs[0], outs[1], ("phi", "alpha", "sigma", "gamma", "prior", "estats")):
+        fin = torch.isfinite(a)
+        assert torch.equal(fin, torch.isfinite(b)), name
+        np.testing.assert_allclose(b[fin].cpu().numpy(), a[fin].cpu().numpy(), rtol=1e-6, atol=1e-6, err_msg=name)
+
+
 def test_frames_coinciding_with_leaf_means():
     """Right after a split the new leaf means ARE data rows (weighted_kmeans): d = 0 exactly.
     The fp32 expansion cancels catastrophically there; the kernel must fall back to direct
