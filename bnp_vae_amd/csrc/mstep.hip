@@ -19,62 +19,14 @@
 // Partial sums are fp32 over at most kMaxChunk frames per wave; everything above that is
 // accumulated in fp64 (LDS across the waves of a workgroup in fixed order, then a fixed-order
 // slab reduction), so results are bit-reproducible run to run.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
-#include "common.h"
+#include "mstep_common.h"
 
 namespace bnpvi {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kStatWaves = 4;          // waves per workgroup
-constexpr int kMaxChunk = 8192;        // frames summed in fp32 before promotion to fp64
-constexpr int kKStep = 16;             // frames per MFMA k-step
-
-union Frag {
-  uint32_t u[4];
-  bf16x8 v;
-};
-
-// exact 3-way bf16 split of 8 fp32 values: x[e] = h[e] + m[e] + l[e]
-__device__ __forceinline__ void split3(const float (&x)[8], Frag& h, Frag& m, Frag& l) {
-  uint32_t hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    const uint32_t u = __float_as_uint(x[e]);
-    hb[e] = u;                                             // top 16 bits are the piece
-    const float r1 = x[e] - __uint_as_float(u & 0xffff0000u);
-    const uint32_t u1 = __float_as_uint(r1);
-    mb[e] = u1;
-    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
-    lb[e] = __float_as_uint(r2);
-  }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    // dword q = {elem 2q (low half), elem 2q+1 (high half)}, each its top 16 bits
-    h.u[q] = __builtin_amdgcn_perm(hb[2 * q + 1], hb[2 * q], 0x07060302u);
-    m.u[q] = __builtin_amdgcn_perm(mb[2 * q + 1], mb[2 * q], 0x07060302u);
-    l.u[q] = __builtin_amdgcn_perm(lb[2 * q + 1], lb[2 * q], 0x07060302u);
-  }
-}
-
-template <int TL, int TD>
-struct RawStep {
-  float a[TL][8];     // phi[frame 8h+e][leaf column of tile a]
-  float b[TD][8];     // Z  [frame 8h+e][dim  column of tile b]
-};
-
-// 6-product accumulate of one (A tile, B tile) pair
-__device__ __forceinline__ void mac6(const Frag& ah, const Frag& am, const Frag& al, const Frag& bh,
-                                     const Frag& bm, const Frag& bl, f32x16& acc) {
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bm.v, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bh.v, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bm.v, acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc, 0, 0, 0);
-}
 
 template <int TL, int TD, bool WANT_Q>
 __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
@@ -376,6 +328,14 @@ int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi,
   if (N == 0) {
     BNPVI_HIP(hipMemsetAsync(stats, 0, (size_t)L * W * sizeof(double), s));
     return BNPVI_OK;
+  }
+  if (!want_q) {
+    // default path: LDS-DMA ring (mstep_dma.hip); BNPVI_MSTEP_PATH=reg keeps the register-streamed kernel
+    const char* force = getenv("BNPVI_MSTEP_PATH");
+    if (!(force && strcmp(force, "reg") == 0)) {
+      const int rc = launch_leaf_stats_dma(ctx, Z, ldz, phi, ldphi, vid, N, D, L, V, stats, mass, s);
+      if (rc != BNPVI_EUNSUPPORTED) return rc;
+    }
   }
   const int tilesL = ldphi / kTile, tilesD = (Dp + kTile - 1) / kTile;
   const bool td2 = tilesD >= 2;
