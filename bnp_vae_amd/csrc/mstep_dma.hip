@@ -148,11 +148,15 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
     if (k < nsteps) issue(k);
 
   for (int64_t ks = 0; ks < nsteps; ++ks) {
-    // the slot of k-step ks has landed when at most the pieces of the younger k-steps are pending
-    if (ks + R - 1 <= nsteps)
-      wait_vmcnt<(R - 2) * P>();
-    else
+    // Refill first: the slot k-step ks+R-1 goes into was consumed a whole iteration ago (all its
+    // LDS reads fed VALU work that has issued since).  Then the slot of k-step ks has landed
+    // once at most the pieces of the R-1 younger k-steps are pending (in-order completion).
+    if (ks + R - 1 < nsteps) {
+      issue(ks + R - 1);
+      wait_vmcnt<(R - 1) * P>();
+    } else {
       wait_vmcnt<0>();
+    }
     const float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
     const int64_t f0 = n0 + ks * kKStep;
     const bool ragged = f0 + kKStep > n1;                       // wave-uniform, last k-step only
@@ -195,8 +199,6 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
         }
       }
     }
-    // every LDS read of the slot refilled below (the one consumed an iteration ago) is long done
-    if (ks + R - 1 < nsteps) issue(ks + R - 1);
 #pragma unroll
     for (int a = 0; a < TL; ++a) {
       Frag ah, am, al;
