@@ -337,3 +337,78 @@ def test_pickle_and_writers(tmp_path):
     lines = (tmp_path / "alpha.txt").read_text().splitlines()
     assert [l.split(' ')[0] for l in lines] == list(g['e0_ids'])
     assert vi.get_true_path_mean([('a', 'b')] * 5).shape == (5, m['D'])
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes: no oracle run is affordable there, so the checks are size-independent
+# properties of one VI iteration (and of its parts) on the synthetic benchmark workload.
+@pytest.mark.parametrize("cfg,N", [("config2", 999_936), ("config3", 262_144)])
+def test_full_size_properties(cfg, N):
+    import torch
+    from bench import CONFIGS, regular_tree, make_latents
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    _n, D, bf, levels = CONFIGS[cfg]
+    parent, is_leaf = regular_tree(bf, levels)
+    K, L = len(parent), int(is_leaf.sum())
+    dev = DeviceVI(device=0)
+    Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, D)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    phi0 = dev.phi[:, :L]
+    assert torch.equal(phi0.sum(dim=1), torch.ones(N, device=dev.device))           # one-hot rows
+    assert torch.all((phi0 == 0) | (phi0 == 1))
+    # nearest leaf indeed (spot check against a torch fp32 distance on a slice)
+    leaves = torch.from_numpy(dev.tree.node_of_leaf.astype(np.int64)).to(dev.device)
+    A = dev.alpha[leaves].to(torch.float32)
+    sl = slice(0, 20000)
+    d2 = torch.cdist(dev.Z[sl, :D], A) ** 2
+    pick = phi0[sl].argmax(dim=1)
+    best = d2.min(dim=1).values
+    assert torch.all(d2.gather(1, pick[:, None])[:, 0] <= best * (1 + 1e-5) + 1e-4)
+
+    for it in range(3):
+        dev.iteration(want_estats=True)
+    torch.cuda.synchronize()
+    phi = dev.phi[:, :L]
+    rows = phi.sum(dim=1, dtype=torch.float64)
+    assert float((rows - 1).abs().max()) < 1e-5                                      # softmax rows
+    assert float(phi.min()) >= 0.0 and bool(torch.all(dev.phi[:, L:] == 0))          # padding stays 0
+    S0e = dev.estats[:, 0]
+    np.testing.assert_allclose(float(S0e.sum()), N, rtol=1e-6)                       # total mass
+    col = phi.sum(dim=0, dtype=torch.float64)
+    np.testing.assert_allclose(S0e.cpu().numpy(), col.cpu().numpy(), rtol=2e-5, atol=1e-3)
+
+    # M-step statistics of that phi: S0 = column sums, per-video masses add up to S0, S1 against a
+    # torch fp64 product on a slice, linearity over a split of the frames
+    dev.leaf_stats(want_q=False, want_mass=True)
+    torch.cuda.synchronize()
+    st, mass = dev.stats.clone(), dev.mass.clone()
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), col.cpu().numpy(), rtol=2e-6, atol=1e-4)
+    # (both are fp64 sums of fp32 partials, grouped differently: per video vs per frame chunk)
+    np.testing.assert_allclose(mass.sum(dim=0).cpu().numpy(), st[:, 0].cpu().numpy(), rtol=2e-6, atol=1e-4)
+    ref = phi.to(torch.float64).T @ dev.Z[:, :D].to(torch.float64)
+    scale = float(ref.abs().max())
+    assert float((st[:, 1:1 + D] - ref).abs().max()) <= 2e-6 * scale
+    half = (N // 512) * 256
+    import ctypes as C
+
+    def part(lo, hi):
+        out = torch.empty_like(st)
+        _lib.check(_lib.lib.bnpvi_leaf_stats(
+            dev.ctx, C.c_void_p(dev.Z.data_ptr() + 4 * lo * dev.Dp), dev.Dp,
+            C.c_void_p(dev.phi.data_ptr() + 4 * lo * dev.tree.Lp), dev.tree.Lp,
+            C.c_void_p(dev.vid.data_ptr() + 4 * lo), hi - lo, D, L, dev.V, 0,
+            C.c_void_p(out.data_ptr()), C.c_void_p(0), dev._stream()))
+        return out
+    both = part(0, half) + part(half, N)
+    torch.cuda.synchronize()
+    # fp32 partials over <=8192-frame chunks fall on different chunk boundaries in the split run
+    assert float((both - st).abs().max()) <= 1e-6 * max(1.0, float(st.abs().max()))
+    # bit-reproducible run to run (fixed-order reductions)
+    dev.leaf_stats(want_q=False, want_mass=False)
+    torch.cuda.synchronize()
+    assert torch.equal(dev.stats, st)
+    dev.close()
