@@ -20,6 +20,15 @@ union Frag {
 
 // exact 3-way bf16 split of 8 fp32 values: x[e] = h[e] + m[e] + l[e]
 __device__ __forceinline__ void split3(const float (&x)[8], Frag& h, Frag& m, Frag& l) {
+#ifdef BNPVI_MABLATE_NOSPLIT
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h.u[q] = __float_as_uint(x[2 * q]);
+    m.u[q] = __float_as_uint(x[2 * q + 1]);
+    l.u[q] = __float_as_uint(x[q]);
+  }
+  return;
+#endif
   uint32_t hb[8], mb[8], lb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -49,6 +58,11 @@ struct RawStep {
 // 6-product accumulate of one (A tile, B tile) pair
 __device__ __forceinline__ void mac6(const Frag& ah, const Frag& am, const Frag& al, const Frag& bh,
                                      const Frag& bm, const Frag& bl, f32x16& acc) {
+#ifdef BNPVI_MABLATE_NOMFMA
+  acc[0] += __uint_as_float((ah.u[0] ^ bl.u[1] ^ am.u[2] ^ bm.u[3] ^ al.u[0] ^ bh.u[1] ^ ah.u[3] ^ bh.u[2] ^
+                             am.u[1] ^ bm.u[0] ^ al.u[2] ^ bl.u[3]) & 0x3fffffffu);
+  return;
+#endif
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc, 0, 0, 0);
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am.v, bm.v, acc, 0, 0, 0);

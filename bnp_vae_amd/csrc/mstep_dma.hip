@@ -146,18 +146,30 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
 #pragma unroll
   for (int k = 0; k < R - 1; ++k)
     if (k < nsteps) issue(k);
+#ifdef BNPVI_MABLATE_NOLOAD
+  // ablation build: every slot holds valid rows (video ids included), the loop loads nothing
+  if (R - 1 < nsteps) issue(R - 1);
+#endif
 
   for (int64_t ks = 0; ks < nsteps; ++ks) {
     // Refill first: the slot k-step ks+R-1 goes into was consumed a whole iteration ago (all its
     // LDS reads fed VALU work that has issued since).  Then the slot of k-step ks has landed
     // once at most the pieces of the R-1 younger k-steps are pending (in-order completion).
+#ifdef BNPVI_MABLATE_NOLOAD
+    wait_vmcnt<0>();
+#else
     if (ks + R - 1 < nsteps) {
       issue(ks + R - 1);
       wait_vmcnt<(R - 1) * P>();
     } else {
       wait_vmcnt<0>();
     }
+#endif
     const float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
+#ifdef BNPVI_MABLATE_NOCOMPUTE
+    s0[0] += slot[lane] + slot[Slot::kA + lane];
+    continue;
+#endif
     const int64_t f0 = n0 + ks * kKStep;
     const bool ragged = f0 + kKStep > n1;                       // wave-uniform, last k-step only
 
@@ -183,19 +195,32 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
     }
     if (lead_dim) {
       const int* vslot = reinterpret_cast<const int*>(slot + Slot::kA + Slot::kB);
+      // Common case (15 of 16 k-steps with 256-frame videos): all 16 frames belong to the video
+      // every lane is already accumulating -- one LDS read and one wave-uniform branch instead
+      // of a read-compare-branch chain per frame.
+      bool same_video = !do_mass;
+      if (do_mass && !ragged) same_video = __ballot(vslot[lane & 15] != my_vid) == 0ull;
+      // S0 takes the same fixed tree sum on both paths (its rounding must not depend on whether
+      // masses were asked for)
+      float t[TL];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (do_mass) {
+      for (int a = 0; a < TL; ++a) {
+        t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
+        s0[a] += t[a];
+      }
+      if (__builtin_expect(same_video, 1)) {
+#pragma unroll
+        for (int a = 0; a < TL; ++a) msum[a] += t[a];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
           const int ve = vslot[8 * h + e];
           if (ve != my_vid && (!ragged || f0 + 8 * h + e < n1)) {   // video boundary
             flush_mass();
             my_vid = ve;
           }
-        }
 #pragma unroll
-        for (int a = 0; a < TL; ++a) {
-          s0[a] += xa[a][e];
-          msum[a] += xa[a][e];
+          for (int a = 0; a < TL; ++a) msum[a] += xa[a][e];
         }
       }
     }

@@ -446,15 +446,184 @@ struct MidArgs {
   float* prior;
   // leaf operands
   int DP, LpPack;
+  int block0_lds;          // workgroup 0 keeps alpha and the tree in LDS (it fits)
   float* a32;
   float* aavec;
   f16x8* apack;
   float* scal;
 };
 
+// Workgroup 0 when K*D doubles + the tree's index arrays fit in LDS: ONE round of global loads
+// (index arrays, old alpha, the leaves' statistics -- none depends on another), after which the
+// level recursion and the operand packing run out of LDS.  Same dataflow as
+// node_params_tree_block: a node reads its parent's OLD alpha and its children's NEW alpha;
+// leaves (no children) therefore go first at any depth, then internal nodes deepest level first.
+__host__ __device__ inline size_t midstep_block0_lds(int K, int L, int D, int nlevels) {
+  return (size_t)K * D * sizeof(double) + (size_t)(5 * K + L + nlevels + 4) * sizeof(int32_t);
+}
+
+__device__ __forceinline__ void params_operands_lds_block(const MidArgs& a, char* smem) {
+  const int K = a.K, D = a.D, L = a.L, W = a.W, T = blockDim.x, tid = threadIdx.x;
+  double* al = reinterpret_cast<double*>(smem);                       // [K][D]
+  int32_t* parent = reinterpret_cast<int32_t*>(al + (size_t)K * D);   // [K]
+  int32_t* leaf_of_node = parent + K;                                  // [K]
+  int32_t* child_ptr = leaf_of_node + K;                               // [K+1]
+  int32_t* child_idx = child_ptr + K + 1;                              // [K]
+  int32_t* level_nodes = child_idx + K;                                // [K]
+  int32_t* level_ptr = level_nodes + K;                                // [nlevels+1]
+  int32_t* node_of_leaf = level_ptr + a.nlevels + 1;                   // [L]
+  __shared__ float red[2][kMidWaves];
+
+  // ---- round 1: every global read of the node update
+  for (int i = tid; i < K; i += T) {
+    parent[i] = a.parent[i];
+    leaf_of_node[i] = a.leaf_of_node[i];
+    child_ptr[i] = a.child_ptr[i];
+    child_idx[i] = i < K - 1 ? a.child_idx[i] : 0;      // K-1 edges
+    level_nodes[i] = a.level_nodes[i];
+  }
+  if (tid == 0) child_ptr[K] = a.child_ptr[K];
+  if (tid <= a.nlevels) level_ptr[tid] = a.level_ptr[tid];
+  for (int i = tid; i < L; i += T) node_of_leaf[i] = a.node_of_leaf[i];
+  for (int e = tid; e < K * D; e += T) al[e] = a.alpha[e];
+  constexpr int kPre = 4;                                 // leaf statistics held in registers
+  double s0[kPre], s1[kPre];
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int e = tid + i * T;
+    s0[i] = s1[i] = 0.0;
+    if (e < L * D) {
+      s0[i] = a.stats[(int64_t)(e / D) * W];
+      s1[i] = a.stats[(int64_t)(e / D) * W + 1 + e % D];
+    }
+  }
+  __syncthreads();
+
+  // ---- leaves
+  auto leaf_update = [&](int e, double S0, double S1) {
+    const int l = e / D, d = e % D;
+    const int k = node_of_leaf[l];
+    const int p = parent[k];
+    const double base = (p < 0) ? (a.alpha0 ? a.alpha0[d] : 0.0) : al[p * D + d];
+    const double s = a.sB + S0 * a.sZ;
+    const double v = (base * a.sB + S1 * a.sZ) / s;
+    a.alpha[(int64_t)k * D + d] = v;
+    if (d == 0) a.sigma[k] = s;
+    return v;
+  };
+  // new leaf values are written to LDS after a barrier: a leaf's parent may (in a one-node tree
+  // only) be absent, but another leaf never reads a leaf -- the barrier is for the fixed-count part
+  double nv[kPre];
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int e = tid + i * T;
+    nv[i] = e < L * D ? leaf_update(e, s0[i], s1[i]) : 0.0;
+  }
+  for (int e = tid + kPre * T; e < L * D; e += T) {
+    const int l = e / D;
+    const double v = leaf_update(e, a.stats[(int64_t)l * W], a.stats[(int64_t)l * W + 1 + e % D]);
+    al[node_of_leaf[l] * D + e % D] = v;     // no reader of a leaf's old value exists
+  }
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int e = tid + i * T;
+    if (e < L * D) al[node_of_leaf[e / D] * D + e % D] = nv[i];
+  }
+  __syncthreads();
+
+  // ---- internal nodes, deepest level first
+  for (int lev = a.nlevels - 1; lev >= 0; --lev) {
+    const int off = level_ptr[lev];
+    const int count = level_ptr[lev + 1] - off;
+    bool any = false;
+    for (int e = tid; e < count * D; e += T) {
+      const int k = level_nodes[off + e / D];
+      if (leaf_of_node[k] >= 0) continue;
+      any = true;
+      const int d = e % D;
+      const int p = parent[k];
+      const double base = (p < 0) ? (a.alpha0 ? a.alpha0[d] : 0.0) : al[p * D + d];
+      const int c0 = child_ptr[k], c1 = child_ptr[k + 1];
+      const double s = (1.0 + (double)(c1 - c0)) * a.sB;
+      double acc = base;
+      for (int c = c0; c < c1; ++c) acc += al[child_idx[c] * D + d];
+      const double v = acc * a.sB / s;
+      al[k * D + d] = v;
+      a.alpha[(int64_t)k * D + d] = v;
+      if (d == 0) a.sigma[k] = s;
+    }
+    (void)any;
+    __syncthreads();
+  }
+
+  // ---- leaf operands of the E-step from the LDS copy (layout: leaf_operands_block)
+  const int DP = a.DP, Lp = a.LpPack;
+  const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  float amax = 0.f, aamax = 0.f;
+  for (int leaf = wave; leaf < Lp; leaf += nw) {
+    const double* row = leaf < L ? al + node_of_leaf[leaf] * D : nullptr;
+    double aa = 0.0;
+    for (int d = lane; d < DP; d += 64) {
+      const float f = (row && d < D) ? (float)row[d] : 0.f;
+      a.a32[(int64_t)leaf * DP + d] = f;
+      aa += (double)f * (double)f;
+      amax = fmaxf(amax, fabsf(f));
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) aa += __shfl_xor(aa, off);
+    if (lane == 0) a.aavec[leaf] = (float)aa;
+    aamax = fmaxf(aamax, (float)aa);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+  if (lane == 0) {
+    red[0][wave] = amax;
+    red[1][wave] = aamax;
+  }
+  __syncthreads();
+  amax = 0.f;
+  aamax = 0.f;
+  for (int w = 0; w < nw; ++w) {
+    amax = fmaxf(amax, red[0][w]);
+    aamax = fmaxf(aamax, red[1][w]);
+  }
+  const int ka = scale_exponent_bits(__float_as_int(amax));
+  if (tid == 0) {
+    a.scal[0] = pow2f(-ka);
+    a.scal[1] = amax;
+    a.scal[2] = aamax;
+  }
+  const int S = DP / 32;
+  const float sa = pow2f(ka);
+  for (int u = tid; u < (Lp / kLT) * S * 2 * 64; u += T) {
+    const int ln = u & 63;
+    const int part = (u >> 6) & 1;
+    const int ts = u >> 7;
+    const int s = ts % S, Tl = ts / S;
+    const int leaf = kLT * Tl + (ln & 15);
+    const int kg = ln >> 4;
+    const double* row = leaf < L ? al + node_of_leaf[leaf] * D : nullptr;
+    f16x8 out;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int dim = 32 * s + 16 * (e >> 2) + 4 * kg + (e & 3);
+      const float v = ((row && dim < D) ? (float)row[dim] : 0.f) * sa;
+      const _Float16 h = (_Float16)v;
+      out[e] = part == 0 ? h : (_Float16)(v - (float)h);
+    }
+    a.apack[u] = out;
+  }
+}
+
+constexpr size_t kMidBlock0LdsMax = 96 * 1024;
+
 __global__ __launch_bounds__(kMidWaves * 64) void midstep_small_kernel(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (blockIdx.x == 0) {
+    if (a.block0_lds) {
+      params_operands_lds_block(a, smem_raw);
+      return;
+    }
     node_params_tree_block(a.level_nodes, a.level_ptr, a.nlevels, a.parent, a.leaf_of_node, a.child_ptr,
                            a.child_idx, a.stats, a.W, a.D, a.sB, a.sZ, a.alpha0, a.alpha, a.sigma);
     leaf_operands_block(a.alpha, a.D, a.DP, a.node_of_leaf, a.L, a.LpPack, a.a32, a.aavec, a.apack, a.scal);
@@ -474,7 +643,7 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
                         double sZ, const double* alpha0, double* alpha, double* sigma, double* mass, int V,
                         double gamma_hyper, double* gamma, float* prior, hipStream_t s) {
   const int DP = bnpvi_padded_dim(D);
-  const size_t lds = (size_t)kMidWaves * (t->L + 2 * t->K) * sizeof(double);
+  size_t lds = (size_t)kMidWaves * (t->L + 2 * t->K) * sizeof(double);
   const bool small = (int64_t)t->K * D <= 64 * 1024 && lds <= 64 * 1024 &&
                      (int64_t)round_up(t->Lp, kLT * kStreamNT) * DP <= 64 * 1024;
   ctx->ops_tree = nullptr;
@@ -494,6 +663,9 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
   a.stats = stats; a.W = W; a.D = D; a.sB = sB; a.sZ = sZ; a.alpha0 = alpha0; a.alpha = alpha; a.sigma = sigma;
   a.mass = mass; a.V = V; a.gamma_hyper = gamma_hyper; a.gamma = gamma; a.prior = prior;
   a.DP = DP; a.LpPack = w.LpPack; a.a32 = w.a32; a.aavec = w.aavec; a.apack = w.apack; a.scal = w.scal;
+  const size_t lds0 = midstep_block0_lds(t->K, t->L, D, t->nlevels);
+  a.block0_lds = lds0 <= kMidBlock0LdsMax && t->nlevels < kMidWaves * 64;
+  if (a.block0_lds && lds0 > lds) lds = lds0;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)midstep_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));

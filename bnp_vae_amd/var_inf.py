@@ -27,7 +27,8 @@ from .node import Node, _DEFAULT
 class VarInf(object):
     def __init__(self, latent_code_size=None, stdev_thr=None, num_splits=None, gamma_hyper=None,
                  sigma_b_sqrinv=None, sigma_z_sqrinv=None, alpha_hyper=None, branching=None,
-                 levels=None, device=None, group=None, retain_internal_phi='auto', verbose=False):
+                 levels=None, device=None, group=None, retain_internal_phi='auto', verbose=False,
+                 path_prior=False):
         # reference attributes (src/var_inf.py:13-21)
         self.root = None
         self.decay_coeff = 0.0
@@ -47,6 +48,7 @@ class VarInf(object):
         self.BF = int(config.resolve('BRANCHING_FACTOR', branching))
         self.levels = int(config.resolve('NUM_LEVELS', levels))
         self.verbose = verbose
+        self.path_prior = bool(path_prior)   # run the branch behind the `continue` at src/var_inf.py:57
         self.pickle_phi = True
         self.retain_internal_phi = retain_internal_phi     # 'auto' | 'always' | 'never'
         # device state
@@ -70,6 +72,8 @@ class VarInf(object):
         self._estats_key = None
         self._estats_host = None
         self._estats_alpha = None
+        self._fpos = None
+        self._fpos_key = None
 
     # ================================================================== helpers
     def _log(self, *a):
@@ -533,10 +537,76 @@ class VarInf(object):
         return VarInf.normalize(np.ones(shape=np.shape(p)))
 
     # ================================================================== accessors
-    def get_true_path_mean(self, x_annot_batch):                 # src/var_inf.py:50-57 (live path)
-        # "standard VAE": the prior mean is zero for every frame (the path-sampling branch
-        # after the `continue` at :57 is unreachable in the reference)
-        return np.zeros(shape=(len(x_annot_batch), self.LATENT_CODE_SIZE))
+    def _frame_index(self):
+        """(vidid, frameid) -> row, the dict form of the reference's `list.index` lookup (:62)."""
+        key = (len(self.vidid_frameid_to_idx), id(self.vidid_frameid_to_idx))
+        if self._fpos is None or self._fpos_key != key:
+            self._fpos = {vf: i for i, vf in reversed(list(enumerate(self.vidid_frameid_to_idx)))}
+            self._fpos_key = key
+        return self._fpos
+
+    def _leaves_bfs(self):
+        """Leaves in the visiting order of get_phi_leaves (src/var_inf.py:40-47)."""
+        out, queue = [], [self.root]
+        while queue:
+            nxt = queue.pop(0)
+            if nxt.isLeafNode:
+                out.append(nxt)
+            else:
+                queue.extend(nxt.children)
+        return out
+
+    def get_true_path_mean(self, x_annot_batch):                 # src/var_inf.py:50-70
+        """Prior mean of every frame of a minibatch.
+
+        Default (`path_prior=False`): the reference's live behaviour -- the "standard VAE" zero
+        mean, because of the `continue` at :57.  With `path_prior=True` the branch behind it runs
+        (:58-68): per frame one leaf is drawn with probability phi[n, .] (renormalised, :65) from
+        NumPy's global stream (one `np.random.choice` per frame, :66) and that leaf's alpha is the
+        mean.  The responsibilities of the whole batch come from the device in one gather.  Leaves
+        are enumerated breadth-first like get_phi_leaves; the reference then goes through a dict
+        keyed by Node objects, whose Python-2 order is address dependent, so which draw selects
+        which leaf is not pinned by the reference -- the distribution is."""
+        B = len(x_annot_batch)
+        zeros = np.zeros(shape=(B, self.LATENT_CODE_SIZE))
+        if not self.path_prior or B == 0:
+            return zeros
+        if len(self.vidid_frameid_to_idx) == 0 or self.root is None:
+            return zeros                                         # "no paths initiated" (:58-60)
+        pos = self._frame_index()
+        rows = np.asarray([pos[(v, f)] for (v, f) in x_annot_batch], dtype=np.int64)
+        leaves = self._leaves_bfs()
+        phi = self._phi_rows(rows, leaves)                       # (B, L) fp64
+        self.last_path_indices = []
+        out = []
+        for b in range(B):
+            values = VarInf.normalize(phi[b])
+            pick = np.random.choice(len(values), p=values)
+            self.last_path_indices.append(int(pick))
+            out.append(np.asarray(leaves[pick].alpha))
+        self._log(self.last_path_indices)
+        return np.asarray(out)
+
+    def _phi_rows(self, rows, leaves):
+        """phi[rows][:, leaves] on the host; one device gather when every leaf's column is live."""
+        import torch
+        dev = self._dev
+        cols, scale = [], []
+        for leaf in leaves:
+            pd = leaf._phi_dev
+            if leaf._phi_host is None and pd is not None and dev is not None and dev.phi is not None \
+                    and pd[0] == self._phi_gen:
+                cols.append(pd[1])
+                scale.append(pd[2])
+            else:
+                cols = None
+                break
+        if cols is None:
+            return np.asarray([[leaf.phi[r][0] for leaf in leaves] for r in rows], dtype=np.float64)
+        r = torch.from_numpy(rows).to(dev.device)
+        c = torch.tensor(cols, dtype=torch.int64, device=dev.device)
+        got = dev.phi.index_select(0, r).index_select(1, c).to('cpu').numpy().astype(np.float64)
+        return got * np.asarray(scale, dtype=np.float64)[None, :]
 
     def get_phi_leaves(self, idx):                               # src/var_inf.py:38-48
         result = {}

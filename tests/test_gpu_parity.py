@@ -339,6 +339,35 @@ def test_pickle_and_writers(tmp_path):
     assert vi.get_true_path_mean([('a', 'b')] * 5).shape == (5, m['D'])
 
 
+def test_path_prior_branch_of_get_true_path_mean():
+    """src/var_inf.py:58-68 (dead behind a `continue` in the reference, optional here): same
+    draws as the oracle from the same global NumPy seed, on the same responsibilities."""
+    g = load("traj_dynamic.npz")
+    m = meta(g)
+    fpv = list(g['fpv'])
+    lc = make_latent_dict(g['Z0'], fpv)
+    vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'], path_prior=True)
+    assert np.all(vi.get_true_path_mean([('x', 0)] * 3) == 0)          # no paths initiated (:58-60)
+    np.random.seed(13)
+    vi.update_variational_parameters(lc)
+    ora = oracle_from_snapshot(snapshot(vi), m['D'], m['thr'], m['num_splits'], fpv)
+    pairs = list(vi.vidid_frameid_to_idx)
+    rs = np.random.RandomState(5)
+    batch = [pairs[i] for i in rs.randint(0, len(pairs), size=64)]
+    np.random.seed(99)
+    got = vi.get_true_path_mean(batch)
+    np.random.seed(99)
+    want = ora.get_true_path_mean(batch, path_prior=True)
+    # the device phi is fp32: a draw can differ only where the uniform variate falls within
+    # rounding of a cumulative-probability boundary
+    same = np.asarray(vi.last_path_indices) == np.asarray(ora.last_path_indices)
+    assert same.mean() >= 0.95
+    np.testing.assert_allclose(got[same], want[same], rtol=PARAM_RTOL, atol=1e-6)
+    assert got.shape == (64, m['D']) and len(set(vi.last_path_indices)) > 1
+    plain = make_vi(latent_code_size=m['D'])
+    assert np.all(plain.get_true_path_mean(batch) == 0)                # the reference's live path
+
+
 # --------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: no oracle run is affordable there, so the checks are size-independent
 # properties of one VI iteration (and of its parts) on the synthetic benchmark workload.

@@ -67,6 +67,76 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ in, float4* 
   if (MODE == 0 && acc == 12345.678f) *sink = acc;
 }
 
+// Two matrices read together (the M-step's shape: phi and Z, 4 KiB of each per 16 frames).
+// ORDER 0: tiles dealt round-robin over all waves (globally sequential sweep);
+// ORDER 1: every wave owns one contiguous range of tiles (as many concurrent streams as waves);
+// ORDER 2: round-robin in blocks of 4 consecutive tiles.
+template <int ORDER, int PF>
+__global__ __launch_bounds__(256) void k2(const float4* __restrict__ a, const float4* __restrict__ b, long ntiles,
+                                           float* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long nw = (long)gridDim.x * 4, w = (long)blockIdx.x * 4 + wave;
+  const long per = (ntiles + nw - 1) / nw;                  // tiles per wave
+  auto tile_of = [&](long j) -> long {                      // j-th tile of this wave, or -1
+    if (j >= per) return -1;
+    long t;
+    if (ORDER == 0) t = j * nw + w;
+    else if (ORDER == 1) t = w * per + j;
+    else t = ((j >> 2) * nw + w) * 4 + (j & 3);
+    return t < ntiles ? t : -1;
+  };
+  float acc = 0.f;
+  float4 ba[PF][4], bb[PF][4];
+#pragma unroll
+  for (int p = 0; p < PF; ++p) {
+    const long t = tile_of(p);
+    if (t >= 0)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ba[p][i] = a[t * 256 + i * 64 + lane];
+        bb[p][i] = b[t * 256 + i * 64 + lane];
+      }
+  }
+  for (long j = 0; j < per; j += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      if (tile_of(j + p) < 0) break;
+      float4 va[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        va[i] = ba[p][i];
+        vb[i] = bb[p][i];
+      }
+      const long tn = tile_of(j + p + PF);
+      if (tn >= 0)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ba[p][i] = a[tn * 256 + i * 64 + lane];
+          bb[p][i] = b[tn * 256 + i * 64 + lane];
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc += va[i].x * vb[i].x + va[i].y * vb[i].y + va[i].z * vb[i].z + va[i].w * vb[i].w;
+    }
+  }
+  if (acc == 12345.678f) *sink = acc;
+}
+
+template <int ORDER, int PF>
+void run2(const char* name, float4* a, float4* b, long ntiles, float* sink, int blocks) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k2<ORDER, PF>), dim3(blocks), dim3(256), 0, 0, a, b, ntiles, sink);
+  CK(hipEventRecord(e0));
+  const int R = 10;
+  for (int i = 0; i < R; ++i) hipLaunchKernelGGL((k2<ORDER, PF>), dim3(blocks), dim3(256), 0, 0, a, b, ntiles, sink);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  ms /= R;
+  const double bytes = (double)ntiles * 4096 * 2;
+  printf("%-28s blocks=%5d  %8.1f us  %7.2f TB/s\n", name, blocks, ms * 1e3, bytes / (ms * 1e-3) / 1e12);
+}
+
 template <int PAT, int MODE, int PF>
 void run(const char* name, float4* a, float4* b, long ntiles, float* sink, int blocks) {
   hipEvent_t e0, e1;
@@ -88,6 +158,17 @@ int main(int argc, char** argv) {
   float4 *a, *b; float* sink;
   CK(hipMalloc(&a, ntiles * 4096)); CK(hipMalloc(&b, ntiles * 4096)); CK(hipMalloc(&sink, 4));
   CK(hipMemset(a, 1, ntiles * 4096)); CK(hipMemset(b, 0, ntiles * 4096));
+  for (int per_cu : {2, 4}) {
+    const int blocks = 256 * per_cu;
+    printf("--- two matrices, %d workgroups (x4 waves) per CU\n", per_cu);
+    run2<0, 1>("read2 round-robin pf1", a, b, ntiles, sink, blocks);
+    run2<1, 1>("read2 chunk/wave  pf1", a, b, ntiles, sink, blocks);
+    run2<2, 1>("read2 rr blocks4  pf1", a, b, ntiles, sink, blocks);
+    run2<0, 2>("read2 round-robin pf2", a, b, ntiles, sink, blocks);
+    run2<1, 2>("read2 chunk/wave  pf2", a, b, ntiles, sink, blocks);
+    run2<2, 2>("read2 rr blocks4  pf2", a, b, ntiles, sink, blocks);
+  }
+  if (argc > 2) return 0;
   for (int per_cu : {2, 4, 8}) {
     const int blocks = 256 * per_cu;
     printf("--- %d workgroups (x4 waves) per CU\n", per_cu);
