@@ -113,22 +113,23 @@ static bool rows_fits(const EstepArgs& a) {
          RowsLds<DP>::bytes(NTp, a.estats != nullptr) <= (size_t)kMaxLdsBytes;
 }
 
-template <int DP, bool STATS>
+template <int DP, bool STATS, int NCH = 0>
 static int launch_rows(const EstepArgs& a) {
+  constexpr int kW = rows_waves(NCH);
   const int L = a.tree->L, Lp = a.tree->Lp;
-  const int NTp = round_up(Lp / kLT, kRChunk);
+  const int NTp = NCH > 0 ? NCH * kRChunk : round_up(Lp / kLT, kRChunk);
   const size_t lds = RowsLds<DP>::bytes(NTp, STATS);
-  auto k = estep_rows_kernel<DP, STATS>;
+  auto k = estep_rows_kernel<DP, STATS, NCH>;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   int per_cu = (int)((size_t)kMaxLdsBytes / lds);
-  per_cu = per_cu < 1 ? 1 : (per_cu > 32 / kRWaves ? 32 / kRWaves : per_cu);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 32 / kW ? 32 / kW : per_cu);
   const int64_t ntiles = ceil_div(a.N, kFT);
   // contiguous tile ranges per workgroup; at most 512 tiles (8192 frames) so that the fp32
   // statistics table of a workgroup stays exact enough before its promotion to fp64
   int64_t tpw = ceil_div(ntiles, (int64_t)a.ctx->num_cu * per_cu);
-  tpw = round_up((int)(tpw < kRWaves ? kRWaves : tpw), kRWaves);
-  if (tpw > 512 / kRWaves * kRWaves) tpw = 512 / kRWaves * kRWaves;
+  tpw = round_up((int)(tpw < kW ? kW : tpw), kW);
+  if (tpw > 512 / kW * kW) tpw = 512 / kW * kW;
   const int64_t blocks = ceil_div(ntiles, tpw);
   double* eslab = nullptr;
   if (STATS) {
@@ -137,13 +138,30 @@ static int launch_rows(const EstepArgs& a) {
     eslab = (double*)a.ctx->slabs.ptr;
   }
   const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
-  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kRWaves * 64), lds, a.stream, a.Z, a.ldz, a.vid, a.N, L,
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kW * 64), lds, a.stream, a.Z, a.ldz, a.vid, a.N, L,
                      Lp, NTp, a.apack, a.aavec, a.a32, a.scal, a.prior, a.half_sz, a.phi, a.logphi, eslab,
                      (int)tpw);
   if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
   BNPVI_LAUNCH_CHECK();
   if (STATS) return estep_reduce_slabs(a, eslab, (int)blocks);
   return BNPVI_OK;
+}
+
+// Row kernel selection: up to 256 leaves (D <= 64), when no statistics are asked for, the logits
+// of a frame stay in registers and the kernel makes one pass (NCH = 2 or 4 chunks of 64 leaves);
+// otherwise two passes.
+template <int DP, bool STATS>
+static int run_rows(const EstepArgs& a) {
+  if constexpr (DP <= 64 && !STATS) {
+    const char* e = getenv("BNPVI_ROWS_PASSES");            // development switch: "2" forces two passes
+    const int chunks = ceil_div(a.tree->Lp, kLT * kRChunk);
+    const bool one = !(e && e[0] == '2');
+    if (one && chunks <= 2 && RowsLds<DP>::bytes(2 * kRChunk, STATS) <= (size_t)kMaxLdsBytes)
+      return launch_rows<DP, STATS, 2>(a);
+    if (one && chunks <= 4 && RowsLds<DP>::bytes(4 * kRChunk, STATS) <= (size_t)kMaxLdsBytes)
+      return launch_rows<DP, STATS, 4>(a);
+  }
+  return launch_rows<DP, STATS, 0>(a);
 }
 
 template <>
@@ -154,7 +172,7 @@ int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   const char* force = getenv("BNPVI_ESTEP_PATH");         // development switch: "rows" | "fused"
   const bool want_rows = force ? strcmp(force, "rows") == 0 : Lp > 64;
   if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
-    return a.estats ? launch_rows<DP, true>(a) : launch_rows<DP, false>(a);
+    return a.estats ? run_rows<DP, true>(a) : run_rows<DP, false>(a);
   if (!hard_stats) {
     // smallest instantiated tile count that covers the padded leaves and fits the LDS
     if (Lp <= 32 && fused_lds_bytes<DP, 2>() <= (size_t)kMaxLdsBytes) return run_fused<DP, 2>(a);

@@ -36,14 +36,23 @@ struct RowsLds {
   }
 };
 
-template <int DP, bool STATS>
-__global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
+// NCH = 0: two passes over any number of 64-leaf chunks.  NCH = 2 or 4 (up to 128 / 256
+// leaves, no statistics): exactly NCH chunks whose logits stay in registers (16 * NCH per lane), ONE pass of
+// MFMAs / distances / square roots (see the body).  512 leaves would need 128 logit registers
+// per lane: measured slower than two passes both at 1 wave per SIMD (no spills) and at 2 (spills).
+constexpr int rows_waves(int NCH) { return NCH >= 4 ? 8 : kRWaves; }
+
+template <int DP, bool STATS, int NCH = 0>
+__global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void estep_rows_kernel(
     const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
     int NTp /* 16-leaf tiles, padded to a multiple of kRChunk */, const f16x8* __restrict__ apack,
     const float* __restrict__ aavec, const float* __restrict__ a32, const float* __restrict__ scal,
     const float* __restrict__ prior, float half_sz, float* __restrict__ phi, float* __restrict__ logphi,
     double* __restrict__ eslab, int tiles_per_wg) {
   constexpr int S = DP / 32;
+  constexpr int kRWaves = rows_waves(NCH);      // shadows the namespace-level default
+  constexpr int kCT = kRChunk;                  // leaf tiles per chunk
+  constexpr int kNChunk = NCH;                  // single-pass variants: chunks per tile
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                    // [NTp*S*2*64]
   float* aa_lds = reinterpret_cast<float*>(a_lds + (size_t)NTp * S * 2 * 64);   // [16*NTp]
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
   const float inv_sa = scal[0];
   const float aamax = scal[2];
   const float c2 = -half_sz * kLog2e;
-  const int nchunk = NTp / kRChunk;
+  const int nchunk = NTp / kCT;
 
   const int64_t ntiles = (N + kFT - 1) / kFT;
   const int64_t t0 = (int64_t)blockIdx.x * tiles_per_wg;
@@ -93,7 +102,9 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
     f16x8 zh[S], zl[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) split8(zA[s], zB[s], pow2f(kz), zh[s], zl[s]);
-    if (tile + kRWaves < t1) load_ztile<DP>(Z, ldz, (tile + kRWaves) * kFT, N, lane, zA, zB);
+    // next tile's Z rows: in flight across the whole tile (two-pass) / issued after phase 1 of the
+    // single-pass variant, whose phase 1 has no registers to spare
+    if (NCH == 0 && tile + kRWaves < t1) load_ztile<DP>(Z, ldz, (tile + kRWaves) * kFT, N, lane, zA, zB);
 
     // the lane's 4 frames (rows 4kg + r): ||z||^2, un-scaling factor, prior row, validity.
     // Frames are handled in PAIRS (r, r+1) on the packed fp32 pipe.
@@ -124,14 +135,14 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
     // log2-unit logits v[t][pair].  No clamp of d at zero: a negative d is below the
     // cancellation bound, so it is replaced by the exact value on the rare path; padded leaves
     // (prior -inf) go through |d|.
-    auto chunk_logits = [&](int ch, f32x2 (&d)[kRChunk][2], f32x2 (&v)[kRChunk][2]) {
+    auto chunk_logits = [&](int ch, f32x2 (&d)[kCT][2], f32x2 (&v)[kCT][2], f32x2 (&pr)[kCT][2]) {
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-      f32x4 acc[kRChunk];
+      f32x4 acc[kCT];
 #pragma unroll
       for (int s = 0; s < S; ++s) {
 #pragma unroll
-        for (int t = 0; t < kRChunk; ++t) {
-          const int T = ch * kRChunk + t;
+        for (int t = 0; t < kCT; ++t) {
+          const int T = ch * kCT + t;
           const f16x8 ah = a_lds[((T * S + s) * 2 + 0) * 64 + lane];
           const f16x8 al = a_lds[((T * S + s) * 2 + 1) * 64 + lane];
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(zl[s], ah, s ? acc[t] : zero4, 0, 0, 0);
@@ -142,18 +153,17 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
 #ifndef BNPVI_ROWS_NO_SCHED
       // issue order: the first k-step's 8 operand reads, then every 3 MFMAs hide the next 2 reads
       // (LDS latency overlaps matrix-pipe time instead of stalling in front of each MFMA)
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * kRChunk, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * kCT, 0);
 #pragma unroll
-      for (int g = 0; g < (S - 1) * kRChunk; ++g) {
+      for (int g = 0; g < (S - 1) * kCT; ++g) {
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 3 * kRChunk, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3 * kCT, 0);
 #endif
-      f32x2 pr[kRChunk][2];
 #pragma unroll
-      for (int t = 0; t < kRChunk; ++t) {
-        const int T = ch * kRChunk + t;
+      for (int t = 0; t < kCT; ++t) {
+        const int T = ch * kCT + t;
         const bool tv = T < tiles_valid;
         if (onevid) {
           const float p = tv ? prow[0][kLT * T] : -INFINITY;
@@ -166,8 +176,8 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
       }
       f32x2 dmin[2] = {{INFINITY, INFINITY}, {INFINITY, INFINITY}};
 #pragma unroll
-      for (int t = 0; t < kRChunk; ++t) {
-        const float aa = aa_lds[kLT * (ch * kRChunk + t) + c];
+      for (int t = 0; t < kCT; ++t) {
+        const float aa = aa_lds[kLT * (ch * kCT + t) + c];
         const f32x2 aa2 = {aa, aa};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -184,8 +194,8 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
         asm volatile("" ::: "memory");      // nothing of the rare path is speculated above the branch
         unsigned pend = 0u;
 #pragma unroll
-        for (int t = 0; t < kRChunk; ++t) {
-          const int leaf = kLT * (ch * kRChunk + t) + c;
+        for (int t = 0; t < kCT; ++t) {
+          const int leaf = kLT * (ch * kCT + t) + c;
           const float aa = aa_lds[leaf];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
           const int idx = __ffs((int)pm) - 1;
           int64_t ns = row0 + 4 * (src >> 4) + (idx & 3);
           if (ns >= N) ns = N - 1;
-          const int leaf = kLT * (ch * kRChunk + (idx >> 2)) + (src & 15);
+          const int leaf = kLT * (ch * kCT + (idx >> 2)) + (src & 15);
           float p = 0.f;
           for (int dd = lane; dd < DP; dd += 64) {
             const float df = Z[ns * ldz + dd] - a32[(int64_t)leaf * DP + dd];
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
           for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off);
           if (lane == src) {
 #pragma unroll
-            for (int t = 0; t < kRChunk; ++t)
+            for (int t = 0; t < kCT; ++t)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
                 if (idx == t * 4 + r) d[t][r >> 1][r & 1] = p;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
         }
       }
 #pragma unroll
-      for (int t = 0; t < kRChunk; ++t)
+      for (int t = 0; t < kCT; ++t)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x2 sq = {__builtin_amdgcn_sqrtf(__builtin_fabsf(d[t][h][0])),
@@ -229,12 +239,91 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
         }
     };
 
+    if constexpr (NCH > 0) {
+      // ---- single pass: every logit of the lane's (leaf column, 4 frames) stays in registers.
+      // Phase 1 computes them (the only MFMAs, distances and square roots) with a running max;
+      // phase 2 sums exp2(v - max); phase 3 normalises and stores.  No statistics here: they
+      // need d next to phi, and every way of having it (recovered from v, per-lane partials,
+      // per-tile cross-lane sums) measured slower than the two-pass kernel, where d is live.
+      static_assert(!STATS, "the single-pass row kernel has no statistics epilogue");
+      f32x2 v[kNChunk][kCT][2];
+      f32x2 m2[2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
+#pragma unroll
+      for (int ch = 0; ch < kNChunk; ++ch) {
+        f32x2 d[kCT][2], pr[kCT][2];
+        chunk_logits(ch, d, v[ch], pr);
+#pragma unroll
+        for (int t = 0; t < kCT; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            m2[h][0] = fmaxf(m2[h][0], v[ch][t][h][0]);
+            m2[h][1] = fmaxf(m2[h][1], v[ch][t][h][1]);
+          }
+        __builtin_amdgcn_sched_barrier(0);       // chunks one after the other: bounded register use
+      }
+      if (tile + kRWaves < t1) load_ztile<DP>(Z, ldz, (tile + kRWaves) * kFT, N, lane, zA, zB);
+      f32x2 M2[2], inv2[2], lse2[2];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) M2[r >> 1][r & 1] = row16_max(m2[r >> 1][r & 1]);   // finite: L >= 1
+      f32x2 ss2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int ch = 0; ch < kNChunk; ++ch)
+#pragma unroll
+        for (int t = 0; t < kCT; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 x = v[ch][t][h] - M2[h];
+            ss2[h] += (f32x2){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float tot = row16_sum(ss2[r >> 1][r & 1]);
+        inv2[r >> 1][r & 1] = okr[r] ? __builtin_amdgcn_rcpf(tot) : 0.f;
+        lse2[r >> 1][r & 1] = __builtin_amdgcn_logf(tot);
+      }
+#pragma unroll
+      for (int ch = 0; ch < kNChunk; ++ch) {
+        f32x2 pv[kCT][2];
+#pragma unroll
+        for (int t = 0; t < kCT; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 x = v[ch][t][h] - M2[h];
+            pv[t][h] = (f32x2){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])} * inv2[h];
+          }
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {
+          const int T = ch * kCT + t;
+          if (T < tiles_valid) {
+            float* tb = phi + row0 * Lp + kLT * T;
+            float* lb = logphi ? logphi + row0 * Lp + kLT * T : nullptr;
+            if (full) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) tb[voff[r]] = pv[t][r >> 1][r & 1];
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (okr[r]) tb[voff[r]] = pv[t][r >> 1][r & 1];
+            }
+            if (lb) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                if (okr[r])
+                  lb[voff[r]] = (v[ch][t][r >> 1][r & 1] - M2[r >> 1][r & 1] - lse2[r >> 1][r & 1]) * kLn2;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      continue;
+    }
+
     // ---- pass 1: online max / sum-exp per frame over the lane's leaf column
     f32x2 m2[2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
     f32x2 ss2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int ch = 0; ch < nchunk; ++ch) {
-      f32x2 d[kRChunk][2], v[kRChunk][2];
-      chunk_logits(ch, d, v);
+      f32x2 d[kCT][2], v[kCT][2], pr[kCT][2];
+      chunk_logits(ch, d, v, pr);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x2 mn;
@@ -249,7 +338,7 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
         const f32x2 resc = m2[h] - sh;
         f32x2 acc2 = ss2[h] * (f32x2){__builtin_amdgcn_exp2f(resc[0]), __builtin_amdgcn_exp2f(resc[1])};
 #pragma unroll
-        for (int t = 0; t < kRChunk; ++t) {
+        for (int t = 0; t < kCT; ++t) {
           const f32x2 x = v[t][h] - sh;
           acc2 += (f32x2){__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
         }
@@ -272,11 +361,11 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
 
     // ---- pass 2: recompute, normalise, accumulate statistics, store
     for (int ch = 0; ch < nchunk; ++ch) {
-      f32x2 d[kRChunk][2], v[kRChunk][2];
-      chunk_logits(ch, d, v);
-      f32x2 pv[kRChunk][2];
+      f32x2 d[kCT][2], v[kCT][2], pr[kCT][2];
+      chunk_logits(ch, d, v, pr);
+      f32x2 pv[kCT][2];
 #pragma unroll
-      for (int t = 0; t < kRChunk; ++t)
+      for (int t = 0; t < kCT; ++t)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const f32x2 x = v[t][h] - M2[h];
@@ -284,8 +373,8 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
         }
       if (STATS) {
 #pragma unroll
-        for (int t = 0; t < kRChunk; ++t) {
-          const int leaf = kLT * (ch * kRChunk + t) + c;
+        for (int t = 0; t < kCT; ++t) {
+          const int leaf = kLT * (ch * kCT + t) + c;
           const f32x2 s0p = pv[t][0] + pv[t][1];
           const f32x2 s2p = pv[t][0] * d[t][0] + pv[t][1] * d[t][1];
           // the 4 lane groups hold different frames of the same leaf
@@ -301,8 +390,8 @@ __global__ __launch_bounds__(kRWaves * 64, kRWaves / 4) void estep_rows_kernel(
       // the other half of each 128-byte line follows with the next leaf tile.  Wave-uniform base
       // (tile row, leaf tile) + a fixed 32-bit lane offset per frame row.
 #pragma unroll
-      for (int t = 0; t < kRChunk; ++t) {
-        const int T = ch * kRChunk + t;
+      for (int t = 0; t < kCT; ++t) {
+        const int T = ch * kCT + t;
         if (T < tiles_valid) {
           float* tb = phi + row0 * Lp + kLT * T;
           float* lb = logphi ? logphi + row0 * Lp + kLT * T : nullptr;

@@ -218,10 +218,13 @@ def test_iteration_against_oracle(N, D, bf, levels, fpv):
     (2000, 32, 5, 3, [256]),          # L=125 (padded 128)
     (1500, 128, 6, 3, [300, 41]),     # L=216, D=128: leaf operands just fit the LDS
     (2100, 64, 9, 2, [64]),           # L=81 (padded 96): last 64-leaf chunk half empty
+    (2300, 64, 16, 2, [128, 77]),     # L=256: single-pass variant with 4 chunks, all full
+    (1900, 48, 6, 3, [90]),           # L=216 (padded 224), D=48 -> 64: 4 chunks, last one ragged
 ])
 def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
-    """Trees with more than 64 leaves take the two-pass row kernel (estep_rows.h) when neither
-    hard mode nor the arg-max is asked for: phi, log phi and the split/merge statistics."""
+    """Trees with more than 64 leaves take the row kernel (estep_rows.h) when neither hard mode nor
+    the arg-max is asked for -- two passes, or one pass with register-resident logits when no
+    statistics are wanted and L <= 256, D <= 64: phi, log phi and the split/merge statistics."""
     ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=9)
     for leaf, col in zip(vi._dfs_leaves(), snapshot(ora)['phi'].T):
         leaf.phi = col.reshape(-1, 1)
@@ -242,6 +245,16 @@ def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
     # without log phi (the production call) the same phi must come out
     vi.compute_phi(Z)
     np.testing.assert_allclose(snapshot(vi)['phi'], pp, rtol=0, atol=1e-6)
+    # and without statistics: up to 256 leaves (D <= 64) that call takes the single-pass variant
+    # (logits in registers); with statistics (above) the two-pass kernel ran
+    dev = vi._dev
+    two_pass = dev.phi.clone()
+    dev.estep(want_stats=False)
+    import torch
+    torch.cuda.synchronize()
+    assert float((dev.phi - two_pass).abs().max()) <= 2e-6
+    logphi2, _ = dev.estep(want_stats=False, want_logphi=True)
+    np.testing.assert_allclose(logphi2.cpu().numpy()[:, :L], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
 
 
 @pytest.mark.parametrize("bf,levels", [(8, 2), (8, 3)])
