@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="config2", choices=sorted(CONFIGS))
-    ap.add_argument("--n", type=int, default=0, help="frames per rank (override)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="frames per rank (override; not `--n`: torch.distributed.run reads that as its own)")
     ap.add_argument("--no-estats", action="store_true",
                     help="skip the split/merge statistics epilogue of the E-step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -117,11 +118,20 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
                   % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    # Rehearsal on a one-GPU box (never the measured configuration): BNPVI_BENCH_REHEARSAL=1 puts
+    # every rank on cuda:0 and uses gloo for the collective, so the N>1 control flow can be run
+    # where RCCL (one device per rank) cannot.
+    rehearsal = world > 1 and os.environ.get("BNPVI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
     from bnp_vae_amd import _lib
@@ -132,8 +142,8 @@ def main():
     if args.config in ("config3", "config4"):
         N = N // world                       # fixed total problem: strong scaling
         scaling = "strong"
-    if args.n:
-        N = args.n
+    if args.frames:
+        N = args.frames
     N = (N // FRAMES_PER_VIDEO) * FRAMES_PER_VIDEO or N     # shards cut on video boundaries
     parent, is_leaf = regular_tree(bf, levels)
     K, L = len(parent), int(is_leaf.sum())
@@ -178,7 +188,7 @@ def main():
     e_ms, m_ms = read(0), read(1)
     _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 0))
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())

@@ -46,11 +46,22 @@ def shard_videos(frames_per_video, world):
     return out
 
 
+def _host_staged(group):
+    """gloo groups (CPU tests, one-GPU rehearsals) get host tensors; RCCL works on the device."""
+    import torch.distributed as dist
+    return dist.get_backend(group) == "gloo"
+
+
 def allreduce_sum_(t, group):
     """In-place sum over ranks (the single per-iteration collective on the statistics buffer)."""
     if world_size(group) > 1:
         import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if t.is_cuda and _host_staged(group):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
 
@@ -60,6 +71,8 @@ def global_count(n_local, group, device):
         return int(n_local), 0
     import torch
     import torch.distributed as dist
+    if _host_staged(group):
+        device = "cpu"
     mine = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
     allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
     dist.all_gather(allv, mine, group=group)
@@ -76,6 +89,8 @@ def select_argmax(score, global_row, group, device):
     import torch
     import torch.distributed as dist
     me = dist.get_rank(group)
+    if _host_staged(group):
+        device = "cpu"
     mine = torch.tensor([float(score), float(global_row), float(me)], dtype=torch.float64, device=device)
     allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
     dist.all_gather(allv, mine, group=group)
@@ -88,5 +103,11 @@ def broadcast_from(t, owner, group):
     """Broadcast `t` from group rank `owner` (the chosen k-means centre row)."""
     if world_size(group) > 1:
         import torch.distributed as dist
-        dist.broadcast(t, src=dist.get_global_rank(group, owner), group=group)
+        src = dist.get_global_rank(group, owner)
+        if t.is_cuda and _host_staged(group):
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=group)
     return t
