@@ -144,7 +144,8 @@ class VarInf(object):
         dev = self._engine()
         if Z is self._Z_host and dev.Z is not None:
             return dev
-        Z = np.asarray(Z)
+        if not hasattr(Z, 'is_cuda'):            # torch tensors (host or device) pass through
+            Z = np.asarray(Z)
         if Z.ndim != 2 or Z.shape[0] != len(self.vidid_frameid_to_idx):
             raise ValueError("latent_codes_matrix has shape %r but %d frames are registered"
                              % (Z.shape, len(self.vidid_frameid_to_idx)))
@@ -313,7 +314,37 @@ class VarInf(object):
     # ================================================================== entry point
     def update_variational_parameters(self, latent_codes):      # src/var_inf.py:84-147
         self._log('Performing variational inference...')
-        Z = self.get_matrix_from_dict(latent_codes)
+        self._update(self.get_matrix_from_dict(latent_codes))
+
+    def update_variational_parameters_matrix(self, Z, keys=None):
+        """The same step for callers that hold the latents as ONE (N, D) matrix -- a NumPy array or
+        a torch tensor, which may already live on the GPU (no host round trip) -- instead of the
+        reference's dict of dicts, whose flattening (src/var_inf.py:72-82) costs more wall-clock
+        than the whole device step from a few 10^5 frames on.  Rows must be in the order
+        get_matrix_from_dict would produce (videos one after the other, frames of a video
+        contiguous).  `keys` = [(vidid, frameid)] per row; required on the first call, which
+        freezes the row order like :73-77, ignored afterwards."""
+        if len(self.vidid_to_idx) == 0:
+            if keys is None:
+                raise ValueError("the first call needs keys = [(vidid, frameid)] per row")
+            keys = list(keys)
+            seen = set()
+            last = object()
+            for vidid, _frameid in keys:
+                if vidid != last:
+                    if vidid in seen:
+                        raise ValueError("frames of video %r are not contiguous rows" % (vidid,))
+                    seen.add(vidid)
+                    self.vidid_to_idx.append(vidid)
+                    last = vidid
+            self.vidid_frameid_to_idx = keys
+        if int(Z.shape[0]) != len(self.vidid_frameid_to_idx):
+            raise ValueError("matrix has %d rows but %d frames are registered"
+                             % (int(Z.shape[0]), len(self.vidid_frameid_to_idx)))
+        self._Z_host = None      # the caller may have rewritten the same matrix in place: always reload
+        self._update(Z)
+
+    def _update(self, Z):
         if self.root is None:
             self._build_initial_tree()
             self._one_hot_init(Z)

@@ -352,6 +352,44 @@ def test_pickle_and_writers(tmp_path):
     assert vi.get_true_path_mean([('a', 'b')] * 5).shape == (5, m['D'])
 
 
+def test_matrix_entry_point_matches_dict_entry_point():
+    """update_variational_parameters_matrix (NumPy matrix, device tensor) walks the same
+    trajectory -- splits and merges included -- as the reference-shaped dict entry point."""
+    import torch
+    g = load("traj_dynamic.npz")
+    m = meta(g)
+    fpv = list(g['fpv'])
+    epochs = [g["Z%d" % e] for e in range(4)]
+    runs = []
+    for kind in ("dict", "numpy", "cuda"):
+        vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+        np.random.seed(13)
+        snaps = []
+        for Z in epochs:
+            lc = make_latent_dict(Z, fpv)
+            if kind == "dict":
+                vi.update_variational_parameters(lc)
+            else:
+                keys = [(v, f) for v in lc for f in lc[v]]
+                rows = np.asarray([lc[v][f] for v, f in keys])
+                if kind == "cuda":
+                    rows = torch.from_numpy(rows).to("cuda:0")
+                vi.update_variational_parameters_matrix(rows, keys=keys)
+            snaps.append(snapshot(vi))
+        runs.append(snaps)
+    for other in runs[1:]:
+        for a, b in zip(runs[0], other):
+            assert list(a['ids']) == list(b['ids'])
+            np.testing.assert_array_equal(a['alpha'], b['alpha'])
+            np.testing.assert_array_equal(a['phi'], b['phi'])
+            np.testing.assert_array_equal(a['gamma'], b['gamma'])
+    vi = make_vi(latent_code_size=m['D'])
+    with pytest.raises(ValueError):
+        vi.update_variational_parameters_matrix(epochs[0])                      # no keys on first call
+    with pytest.raises(ValueError):
+        vi.update_variational_parameters_matrix(epochs[0][:3], keys=[(0, 0), (1, 0), (0, 1)])
+
+
 def test_path_prior_branch_of_get_true_path_mean():
     """src/var_inf.py:58-68 (dead behind a `continue` in the reference, optional here): same
     draws as the oracle from the same global NumPy seed, on the same responsibilities."""
