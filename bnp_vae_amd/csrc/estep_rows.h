@@ -18,6 +18,8 @@
 // HBM traffic is the algorithmic minimum: Z read once, phi written once (no logits round trip).
 #pragma once
 
+#include <type_traits>
+
 #include "estep_kernels.h"
 
 namespace bnpvi {
@@ -135,7 +137,33 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
     // log2-unit logits v[t][pair].  No clamp of d at zero: a negative d is below the
     // cancellation bound, so it is replaced by the exact value on the rare path; padded leaves
     // (prior -inf) go through |d|.
-    auto chunk_logits = [&](int ch, f32x2 (&d)[kCT][2], f32x2 (&v)[kCT][2], f32x2 (&pr)[kCT][2]) {
+    // full_c: every tile of the chunk is a valid leaf tile (all chunks but possibly the last): no
+    // per-entry select of -inf priors.  screen_c: run the cancellation screen; pass 2 drops it
+    // when pass 1 (same arithmetic, same values) found nothing in the whole tile.  Returns
+    // whether the screen fired (wave-uniform).
+    auto chunk_logits = [&](auto full_c, auto screen_c, int ch, f32x2 (&d)[kCT][2], f32x2 (&v)[kCT][2],
+                            f32x2 (&pr)[kCT][2]) -> bool {
+      constexpr bool kFullChunk = decltype(full_c)::value;
+      constexpr bool kScreen = decltype(screen_c)::value;
+      // the chunk's prior entries first: their L2 round trip runs under the MFMA block (padded
+      // tiles read the last valid tile's address and are overwritten with -inf below)
+      float prv[kCT][4];
+      if (onevid) {
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {
+          const int T = ch * kCT + t;
+          const float p = prow[0][kLT * (T < tiles_valid ? T : tiles_valid - 1)];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prv[t][r] = p;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < kCT; ++t) {
+          const int T = ch * kCT + t;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prv[t][r] = prow[r][kLT * (T < tiles_valid ? T : tiles_valid - 1)];
+        }
+      }
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 acc[kCT];
 #pragma unroll
@@ -164,15 +192,9 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
 #pragma unroll
       for (int t = 0; t < kCT; ++t) {
         const int T = ch * kCT + t;
-        const bool tv = T < tiles_valid;
-        if (onevid) {
-          const float p = tv ? prow[0][kLT * T] : -INFINITY;
-          pr[t][0] = (f32x2){p, p};
-          pr[t][1] = (f32x2){p, p};
-        } else {
+        const bool tv = kFullChunk || T < tiles_valid;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pr[t][r >> 1][r & 1] = tv ? prow[r][kLT * T] : -INFINITY;
-        }
+        for (int r = 0; r < 4; ++r) pr[t][r >> 1][r & 1] = tv ? prv[t][r] : -INFINITY;
       }
       f32x2 dmin[2] = {{INFINITY, INFINITY}, {INFINITY, INFINITY}};
 #pragma unroll
@@ -183,14 +205,18 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
         for (int h = 0; h < 2; ++h) {
           const f32x2 a2 = {acc[t][2 * h], acc[t][2 * h + 1]};
           d[t][h] = un2[h] * a2 + zz2[h] + aa2;
-          dmin[h][0] = fminf(dmin[h][0], d[t][h][0]);
-          dmin[h][1] = fminf(dmin[h][1], d[t][h][1]);
+          if (kScreen) {
+            dmin[h][0] = fminf(dmin[h][0], d[t][h][0]);
+            dmin[h][1] = fminf(dmin[h][1], d[t][h][1]);
+          }
         }
       }
+      bool fired = false;
       // cancellation screen (see estep_kernels.h): rare exact recomputation by direct differences
       const bool sus = (dmin[0][0] < thr2[0][0]) | (dmin[0][1] < thr2[0][1]) | (dmin[1][0] < thr2[1][0]) |
                        (dmin[1][1] < thr2[1][1]);
-      if (__builtin_expect(__ballot(sus) != 0ull, 0)) {
+      if (kScreen && __builtin_expect(__ballot(sus) != 0ull, 0)) {
+        fired = true;
         asm volatile("" ::: "memory");      // nothing of the rare path is speculated above the branch
         unsigned pend = 0u;
 #pragma unroll
@@ -237,6 +263,14 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
                             __builtin_amdgcn_sqrtf(__builtin_fabsf(d[t][h][1]))};
           v[t][h] = c22 * sq + pr[t][h];
         }
+      return fired;
+    };
+    auto run_chunk = [&](bool screen, int ch, f32x2 (&d)[kCT][2], f32x2 (&v)[kCT][2], f32x2 (&pr)[kCT][2]) -> bool {
+      using Yes = std::true_type;
+      using No = std::false_type;
+      const bool full_chunk = (ch + 1) * kCT <= tiles_valid;          // wave-uniform
+      if (screen) return full_chunk ? chunk_logits(Yes{}, Yes{}, ch, d, v, pr) : chunk_logits(No{}, Yes{}, ch, d, v, pr);
+      return full_chunk ? chunk_logits(Yes{}, No{}, ch, d, v, pr) : chunk_logits(No{}, No{}, ch, d, v, pr);
     };
 
     if constexpr (NCH > 0) {
@@ -251,7 +285,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
 #pragma unroll
       for (int ch = 0; ch < kNChunk; ++ch) {
         f32x2 d[kCT][2], pr[kCT][2];
-        chunk_logits(ch, d, v[ch], pr);
+        run_chunk(true, ch, d, v[ch], pr);
 #pragma unroll
         for (int t = 0; t < kCT; ++t)
 #pragma unroll
@@ -319,11 +353,12 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
     }
 
     // ---- pass 1: online max / sum-exp per frame over the lane's leaf column
+    bool tile_sus = false;             // wave-uniform: the cancellation screen fired somewhere in this tile
     f32x2 m2[2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
     f32x2 ss2[2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (int ch = 0; ch < nchunk; ++ch) {
       f32x2 d[kCT][2], v[kCT][2], pr[kCT][2];
-      chunk_logits(ch, d, v, pr);
+      tile_sus |= run_chunk(true, ch, d, v, pr);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         f32x2 mn;
@@ -362,7 +397,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
     // ---- pass 2: recompute, normalise, accumulate statistics, store
     for (int ch = 0; ch < nchunk; ++ch) {
       f32x2 d[kCT][2], v[kCT][2], pr[kCT][2];
-      chunk_logits(ch, d, v, pr);
+      run_chunk(tile_sus, ch, d, v, pr);
       f32x2 pv[kCT][2];
 #pragma unroll
       for (int t = 0; t < kCT; ++t)
