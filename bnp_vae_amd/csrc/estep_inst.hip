@@ -9,6 +9,10 @@
 #error "compile with -DBNPVI_DP=<padded latent dim>"
 #endif
 
+#ifndef BNPVI_FUSED_PF_SMALL
+#define BNPVI_FUSED_PF_SMALL 1
+#endif
+
 namespace bnpvi {
 
 template <int DP, int NT>
@@ -38,8 +42,11 @@ static int resident_blocks(const void* kern, size_t lds, int* out) {
 
 template <int DP, int NT, bool HARD, bool STATS>
 static int launch_fused(const EstepArgs& a) {
-  // two Z tiles in flight per wave where a tile is cheap to hold (16 registers at DP = 64)
-  constexpr int PF = (DP <= 64 && NT <= 4) ? 2 : 1;
+  // Z tiles in flight per wave.  At DP = 64, NT <= 4 a second tile (16 registers) measured 5 % faster
+  // until the prior entries were requested ahead of the MFMA block (another 16 registers held
+  // across it): with both the kernel spills at 3 waves per SIMD; priors early + one tile wins
+  // (106.6 us against 109-110 us; both at 2 waves per SIMD: 114 us).
+  constexpr int PF = (DP <= 64 && NT <= 4) ? BNPVI_FUSED_PF_SMALL : 1;
   const int L = a.tree->L, Lp = a.tree->Lp;
   const size_t lds = fused_lds_bytes<DP, NT>();
   auto k = estep_fused_kernel<DP, NT, PF, HARD, STATS>;

@@ -110,13 +110,19 @@ __device__ __forceinline__ void load_ztile(const float* __restrict__ Z, int ldz,
 
 // next_row0 >= 0: once zA/zB are converted they are reloaded with the rows of that later tile
 // (software prefetch: the loads are in flight during this tile's MFMAs and epilogue).
-template <int DP, int NT>
+struct NoLoads {
+  __device__ __forceinline__ void operator()() const {}
+};
+
+// more_loads(): further global loads of the caller, issued together with the next tile's Z rows
+// (after this tile's rows have been consumed, before the MFMA block that hides their latency).
+template <int DP, int NT, class MoreLoads = NoLoads>
 __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int ldz, int64_t row0,
                                                int64_t N, float4 (&zA)[DP / 32],
                                                float4 (&zB)[DP / 32], int64_t next_row0,
                                                const LeafOperands& lo_,
                                                int lane, int tiles_valid, int lvalid,
-                                               f32x4 (&acc)[NT]) {
+                                               f32x4 (&acc)[NT], MoreLoads more_loads = MoreLoads()) {
   constexpr int S = DP / 32;
   const int kg = lane >> 4;
   float zz = 0.f, amax = 0.f;
@@ -139,6 +145,7 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
 #ifndef BNPVI_LATE_PREFETCH
   if (next_row0 >= 0) load_ztile<DP>(Z, ldz, next_row0, N, lane, zA, zB);
 #endif
+  more_loads();
 
   // every tile's MFMAs run unconditionally (operands of tiles past the padded leaves are zero)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -360,8 +367,9 @@ __device__ __forceinline__ void tile_epilogue_generic(const FusedParams& p, int6
 // pairs of entries on the packed fp32 pipe, one store block per frame.
 template <int NT, int TV, bool STATS>
 __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t n, bool ok, int lane,
-                                                   int tiles_valid, const float* prow, f32x4 (&d2)[NT],
-                                                   float (&s0)[STATS ? NT : 1][4],
+                                                   int tiles_valid, const float* prow,
+                                                   const float4 (&pre)[NT] /* prior entries, TV > 0 only */,
+                                                   f32x4 (&d2)[NT], float (&s0)[STATS ? NT : 1][4],
                                                    float (&s2)[STATS ? NT : 1][4]) {
   const int kg = lane >> 4;
   const float c2 = -p.half_sz * kLog2e;
@@ -370,7 +378,10 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     float4 p4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (TV > 0 || T < tiles_valid) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+    if (TV > 0)
+      p4 = pre[T];
+    else if (T < tiles_valid)
+      p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
     lg[T][0] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][0]), p4.x);
     lg[T][1] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][1]), p4.y);
     lg[T][2] = fmaf(c2, __builtin_amdgcn_sqrtf(d2[T][2]), p4.z);
@@ -433,30 +444,49 @@ template <int DP, int NT, bool HARD, bool STATS>
 __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOperands& lo_, int64_t tile,
                                            int64_t next_tile, int64_t ntiles, int lane, int tiles_valid,
                                            float4 (&zA)[DP / 32], float4 (&zB)[DP / 32],
+                                           int& vcur /* in: video of this tile's frame (lane & 15);
+                                                        out: the same for next_tile */,
                                            float (&s0)[STATS ? NT : 1][4], float (&s2)[STATS ? NT : 1][4]) {
   // NT <= 4 is only dispatched with every tile valid (Lp = 16 NT): compile-time tile count there
   constexpr int TV = NT <= 4 ? NT : 0;
   const int j = lane & 15;
   const int64_t n = tile * kFT + j;
   const bool ok = n < p.N;
-  const int64_t nn = ok ? n : p.N - 1;
 #ifdef BNPVI_ABLATE_NOPRIOR
   const float* prow = p.prior;
 #else
-  const float* prow = HARD ? nullptr : p.prior + (int64_t)p.vid[nn] * p.Lp;
+  const float* prow = HARD ? nullptr : p.prior + (int64_t)vcur * p.Lp;
 #endif
+  const bool soft_only = !(HARD || p.logphi != nullptr || p.assign != nullptr);   // wave-uniform
+  // The video index came with the previous tile's prefetch, so the prior entries are requested
+  // BEFORE the MFMA block (with the next tile's Z rows and video index): their L2 round trip
+  // runs under the MFMAs instead of in front of the epilogue.
+  float4 pre[NT];
+  auto more_loads = [&]() {
+    if (TV > 0 && soft_only) {
+#pragma unroll
+      for (int T = 0; T < NT; ++T) pre[T] = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * (lane >> 4));
+    }
+    if (!HARD && next_tile < ntiles) {
+      const int64_t n2 = next_tile * kFT + j;
+      vcur = p.vid[n2 < p.N ? n2 : p.N - 1];
+    }
+  };
   f32x4 d2[NT];
   tile_distances<DP, NT>(p.Z, p.ldz, tile * kFT, p.N, zA, zB, next_tile < ntiles ? next_tile * kFT : -1,
-                         lo_, lane, tiles_valid, p.L, d2);
-  if (HARD || p.logphi != nullptr || p.assign != nullptr)
+                         lo_, lane, tiles_valid, p.L, d2, more_loads);
+  if (!soft_only)
     tile_epilogue_generic<NT, HARD, STATS>(p, n, ok, lane, tiles_valid, prow, d2, s0, s2);
   else
-    tile_epilogue_soft<NT, TV, STATS>(p, n, ok, lane, tiles_valid, prow, d2, s0, s2);
+    tile_epilogue_soft<NT, TV, STATS>(p, n, ok, lane, tiles_valid, prow, pre, d2, s0, s2);
 }
 
+#ifndef BNPVI_FUSED_MINW_SMALL
+#define BNPVI_FUSED_MINW_SMALL 3
+#endif
 // waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane)
 constexpr int fused_min_waves(int DP, int NT) {
-  return (NT <= 4 && DP <= 64) ? 3 : (NT <= 8 && DP <= 128) ? 2 : 1;
+  return (NT <= 4 && DP <= 64) ? BNPVI_FUSED_MINW_SMALL : (NT <= 8 && DP <= 128) ? 2 : 1;
 }
 
 template <int DP, int NT, int PF, bool HARD, bool STATS>
@@ -504,20 +534,27 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
 
   int64_t tile = (int64_t)blockIdx.x * kEWaves + wave;
   float4 zA0[S], zB0[S], zA1[PF == 2 ? S : 1], zB1[PF == 2 ? S : 1];
-  if (tile < ntiles) load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA0, zB0);
+  int vcur0 = 0, vcur1 = 0;
+  if (tile < ntiles) {
+    load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA0, zB0);
+    if (!HARD) vcur0 = vid[tile * kFT + j < N ? tile * kFT + j : N - 1];
+  }
   if constexpr (PF == 2) {
-    if (tile + stride < ntiles) load_ztile<DP>(Z, ldz, (tile + stride) * kFT, N, lane, zA1, zB1);
+    if (tile + stride < ntiles) {
+      load_ztile<DP>(Z, ldz, (tile + stride) * kFT, N, lane, zA1, zB1);
+      if (!HARD) vcur1 = vid[(tile + stride) * kFT + j < N ? (tile + stride) * kFT + j : N - 1];
+    }
   }
   while (tile < ntiles) {
     fused_tile<DP, NT, HARD, STATS>(p, lo_, tile, tile + PF * stride, ntiles, lane, tiles_valid, zA0, zB0,
-                                    s0, s2);
+                                    vcur0, s0, s2);
     tile += stride;
     if constexpr (PF == 2) {
       if (tile >= ntiles) break;
       // keep the two copies of the body apart: interleaved they need twice the registers
       __builtin_amdgcn_sched_barrier(0);
       fused_tile<DP, NT, HARD, STATS>(p, lo_, tile, tile + PF * stride, ntiles, lane, tiles_valid, zA1,
-                                      zB1, s0, s2);
+                                      zB1, vcur1, s0, s2);
       tile += stride;
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -224,6 +224,15 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
       for (int a = 0; a < TL; ++a) {
         t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
         s0[a] += t[a];
+        // Keep the S0 update HERE, in straight-line code ahead of the divergent video-boundary
+        // path.  Left to the compiler it is sunk behind that path (packed add with op_sel right
+        // after the exec-mask restores and a taken branch), and there S0 of lanes 16-31 lost
+        // whole k-steps once in ~1000 launches on MI355X (S1, from the same registers through
+        // the MFMAs, never did): tools/mstress3.py, 12 of 10000 launches without the pin, 0 of
+        // 17500 with it.  -DBNPVI_NO_S0_PIN rebuilds the failing variant.
+#ifndef BNPVI_NO_S0_PIN
+        asm volatile("" : "+v"(s0[a]));
+#endif
       }
       if (__builtin_expect(same_video, 1)) {
 #pragma unroll
@@ -255,7 +264,11 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
   //      memory is free now
   __syncthreads();
   double* acc_lds = reinterpret_cast<double*>(smem_raw);          // [TL*TD][16][64]
+#ifdef BNPVI_S0_OUTSIDE_RING
+  double* s0_lds = reinterpret_cast<double*>(smem_raw + (size_t)kDmaWaves * R * Slot::kFloats * sizeof(float));
+#else
   double* s0_lds = acc_lds + TL * TD * 16 * 64;                   // [TL][32]
+#endif
   for (int w = 0; w < kDmaWaves; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -307,6 +320,9 @@ static int run_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, in
   using Slot = DmaSlot<TL, TD>;
   const int gy = tilesL / TL, gz = tilesD / TD;
   size_t lds = (size_t)kDmaWaves * R * Slot::kFloats * sizeof(float);
+#ifdef BNPVI_S0_OUTSIDE_RING
+  lds += TL * 32 * sizeof(double);
+#endif
   const size_t comb = (size_t)(TL * TD * 16 * 64 + TL * 32) * sizeof(double);
   if (lds < comb) lds = comb;
   int per_cu = (int)((size_t)kMaxLdsBytes / lds);

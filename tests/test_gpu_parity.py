@@ -352,6 +352,40 @@ def test_pickle_and_writers(tmp_path):
     assert vi.get_true_path_mean([('a', 'b')] * 5).shape == (5, m['D'])
 
 
+def test_mstep_bit_reproducible_behind_the_estep():
+    """E-step then M-step, 400 times on fixed parameters (config-3 shape): phi is rewritten with
+    the same values each time, so every M-step result must equal the first bit for bit.  Guards
+    the S0 accumulation of mstep_dma.hip, which once lost k-steps in ~1 of 1000 launches."""
+    import torch
+    from bench import CONFIGS, regular_tree, make_latents
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    _n, D, bf, levels = CONFIGS["config3"]
+    N = 262_144
+    parent, is_leaf = regular_tree(bf, levels)
+    K, L = len(parent), int(is_leaf.sum())
+    dev = DeviceVI(device=0)
+    Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, D)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    for _ in range(3):
+        dev.iteration(want_estats=True)
+    first, differ = None, 0
+    for _ in range(400):
+        dev.estep(want_stats=True)
+        dev.leaf_stats(want_q=False, want_mass=True)
+        if first is None:
+            first = dev.stats.clone()
+        else:
+            differ += int(not torch.equal(dev.stats, first))
+    col = dev.phi[:, :L].sum(dim=0, dtype=torch.float64)
+    assert differ == 0
+    np.testing.assert_allclose(first[:, 0].cpu().numpy(), col.cpu().numpy(), rtol=2e-6, atol=1e-4)
+    dev.close()
+
+
 def test_matrix_entry_point_matches_dict_entry_point():
     """update_variational_parameters_matrix (NumPy matrix, device tensor) walks the same
     trajectory -- splits and merges included -- as the reference-shaped dict entry point."""
