@@ -26,6 +26,19 @@ for r in range(reps):
     dev.estep(want_stats=True)
     dev.leaf_stats(want_q=False, want_mass=want_mass)
     st = dev.stats.clone()
+    if want_mass:
+        mk = dev.mass.clone()
+        if first is None:
+            mass0 = mk
+        else:
+            md = float((mk - mass0).abs().max())
+            if md > 1e-9:
+                bad_mass = globals().get("bad_mass", 0) + 1
+                globals()["bad_mass"] = bad_mass
+                if bad_mass <= 4:
+                    nz = torch.nonzero((mk - mass0).abs() > 1e-9)
+                    print("rep %d: per-video masses differ by up to %.3e in %d entries, e.g. (video, leaf) %s"
+                          % (r, md, nz.shape[0], nz[:6].tolist()))
     if first is None:
         first = st
     elif not torch.equal(st, first):
@@ -35,5 +48,5 @@ for r in range(reps):
         if bad <= 4:
             print("rep %d: %d entries differ; leaves %s; columns %s; max %.3e" % (
                 r, nz.shape[0], sorted(set(nz[:, 0].tolist()))[:20], sorted(set(nz[:, 1].tolist()))[:8], float(dd.max())))
-print("%s N=%d mass=%s order=%s: %d of %d repetitions differ from the first" % (
-    cfg, N, want_mass, os.environ.get("BNPVI_MSTEP_ORDER", "default"), bad, reps))
+print("%s N=%d mass=%s order=%s: %d of %d repetitions differ from the first; masses off in %d" % (
+    cfg, N, want_mass, os.environ.get("BNPVI_MSTEP_ORDER", "default"), bad, reps, globals().get("bad_mass", 0)))
