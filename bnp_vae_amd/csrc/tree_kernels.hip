@@ -198,19 +198,33 @@ int launch_gamma_update(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* mass,
 // digamma for x >= 1 (arguments here are 1+mass, GAMMA+mass and their sum): upward recurrence
 // to x >= 10, then the asymptotic series through x^-14 (truncation < 5e-17).
 // ------------------------------------------------------------------------------------------
+// 1/x for x >= 1 without the IEEE division sequence: hardware estimate + two Newton steps
+// (relative error ~1e-16; the scaling / fix-up steps of a full division are not needed for
+// normal, finite arguments).
+__device__ __forceinline__ double recip_pos(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
 __device__ double digamma_pos(double x) {
+#ifdef BNPVI_TABLATE_NODIGAMMA
+  return x * 0.5;
+#endif
   double r = 0.0;
   while (x < 10.0) {
-    r -= 1.0 / x;
+    r -= recip_pos(x);
     x += 1.0;
   }
-  const double f = 1.0 / (x * x);
+  const double rx = recip_pos(x);
+  const double f = rx * rx;
   const double t =
       f * (-1.0 / 12.0 +
            f * (1.0 / 120.0 +
                 f * (-1.0 / 252.0 +
                      f * (1.0 / 240.0 + f * (-1.0 / 132.0 + f * (691.0 / 32760.0 + f * (-1.0 / 12.0)))))));
-  return r + log(x) - 0.5 / x + t;
+  return r + log(x) - 0.5 * rx + t;
 }
 
 // One workgroup per video.  e0[k] = psi(g0)-psi(g0+g1), e1[k] = psi(g1)-psi(g0+g1), root = 0.
@@ -364,6 +378,10 @@ __device__ __forceinline__ void stick_wave_video(
   wave_inclusive_scan(P, K, lane);
 
   double best = -INFINITY;
+#ifdef BNPVI_TABLATE_NOPRIORPASS
+  for (int l = lane; l < Lp; l += 64) prior[(int64_t)v * Lp + l] = l < L ? (float)P[node_of_leaf[l] > 0 ? 1 : 0] : -INFINITY;
+  return;
+#endif
   for (int pass = 0; pass < 2; ++pass) {
     for (int l = lane; l < Lp; l += 64) {
       if (l >= L) {
@@ -620,6 +638,9 @@ constexpr size_t kMidBlock0LdsMax = 96 * 1024;
 __global__ __launch_bounds__(kMidWaves * 64) void midstep_small_kernel(MidArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if (blockIdx.x == 0) {
+#ifdef BNPVI_TABLATE_NOBLOCK0
+    return;
+#endif
     if (a.block0_lds) {
       params_operands_lds_block(a, smem_raw);
       return;

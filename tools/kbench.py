@@ -43,6 +43,7 @@ def main():
         ("gamma_update", dev.gamma_update),
         ("prior_table", dev.prior_table),
         ("gamma_prior", dev.gamma_prior),
+        ("params_prior", dev.params_prior),
         ("estep", lambda: dev.estep(want_stats=False)),
         ("estep_stats", lambda: dev.estep(want_stats=True)),
         ("estep_logphi", lambda: dev.estep(want_stats=False, want_logphi=True)),
