@@ -195,6 +195,95 @@ __global__ __launch_bounds__(256) void estep_normalize_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streamed regime, pass B for the production call (soft mode, no arg-max), in two kernels with no
+// atomics: (1) per row, combine the chunk partials into (max, log-sum-exp); (2) normalise the
+// matrix by COLUMN WINDOWS -- a lane owns 4 fixed leaves of a 256-leaf window and walks a block
+// of rows, so the statistics S0' / S2 of its leaves stay in registers; the 4 waves of a
+// workgroup are combined in fixed order and written as one fp64 slab per row block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void estep_rowstat_kernel(const float2* __restrict__ part, int nchunk,
+                                                            int64_t N, float2* __restrict__ rowstat) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float m = -INFINITY;
+  for (int c = lane; c < nchunk; c += 64) m = fmaxf(m, part[n * nchunk + c].x);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+  float ssum = 0.f;
+  for (int c = lane; c < nchunk; c += 64) {
+    const float2 p = part[n * nchunk + c];
+    if (p.x != -INFINITY) ssum += p.y * __builtin_amdgcn_exp2f((p.x - m) * kLog2e);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) ssum += __shfl_xor(ssum, off);
+  if (lane == 0) rowstat[n] = make_float2(m, __builtin_amdgcn_logf(ssum) * kLn2);
+}
+
+constexpr int kNormRows = 512;      // rows per workgroup (4 waves x 128)
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void estep_normalize_cols_kernel(
+    float* __restrict__ phi, float* __restrict__ logphi, const float2* __restrict__ rowstat,
+    const float* __restrict__ prior, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
+    float inv_half_sz, double* __restrict__ eslab /* [row blocks][L][2] */) {
+  __shared__ float comb[4][256][8];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int c4 = blockIdx.x * 256 + lane * 4;            // this lane's 4 leaves
+  const bool col_ok = c4 < Lp;                           // Lp is a multiple of 4
+  const int64_t r0 = (int64_t)blockIdx.y * kNormRows;
+  const int64_t r1 = r0 + kNormRows < N ? r0 + kNormRows : N;
+  float s0[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (col_ok) {
+#pragma unroll 2
+    for (int64_t n = r0 + wave; n < r1; n += 4) {
+      const float2 rs = rowstat[n];
+      const float4 x = *reinterpret_cast<const float4*>(phi + n * Lp + c4);
+      float4 pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (STATS) pr = *reinterpret_cast<const float4*>(prior + (int64_t)vid[n] * Lp + c4);
+      const float xv[4] = {x.x, x.y, x.z, x.w};
+      const float prv[4] = {pr.x, pr.y, pr.z, pr.w};
+      float pv[4], lv[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        lv[c] = (xv[c] - rs.x) - rs.y;
+        pv[c] = __builtin_amdgcn_exp2f(lv[c] * kLog2e);
+        if (STATS) {
+          const float d = (prv[c] * kLn2 - xv[c]) * inv_half_sz;     // logit = prior*ln2 - half_sz*d
+          s0[c] += pv[c];
+          s2[c] += pv[c] != 0.f ? pv[c] * (d * d) : 0.f;             // padded leaves: 0 * inf
+        }
+      }
+      *reinterpret_cast<float4*>(phi + n * Lp + c4) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      if (logphi) *reinterpret_cast<float4*>(logphi + n * Lp + c4) = make_float4(lv[0], lv[1], lv[2], lv[3]);
+    }
+  }
+  if (STATS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      comb[wave][lane][c] = s0[c];
+      comb[wave][lane][4 + c] = s2[c];
+    }
+    __syncthreads();
+    // thread t of the workgroup owns leaf (window, t): lane t/4, component t%4
+    const int t = threadIdx.x;
+    const int leaf = blockIdx.x * 256 + t;
+    if (leaf < L) {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        a += (double)comb[w][t >> 2][t & 3];
+        b += (double)comb[w][t >> 2][4 + (t & 3)];
+      }
+      double* out = eslab + ((int64_t)blockIdx.y * L + leaf) * 2;
+      out[0] = a;
+      out[1] = b;
+    }
+  }
+}
+
 int estep_reduce_slabs(const EstepArgs& a, const double* eslab, int nslab) {
   const int elems = 2 * a.tree->L;
   return launch_slab_reduce(eslab, nslab, elems, a.estats, a.stream);
@@ -202,6 +291,28 @@ int estep_reduce_slabs(const EstepArgs& a, const double* eslab, int nslab) {
 
 int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {
   const int L = a.tree->L, Lp = a.tree->Lp;
+  if (a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr) {
+    float2* rowstat = const_cast<float2*>(part) + (size_t)a.N * nchunk;     // room reserved by run_streamed
+    hipLaunchKernelGGL(estep_rowstat_kernel, dim3((unsigned)ceil_div(a.N, 4)), dim3(256), 0, a.stream, part,
+                       nchunk, a.N, rowstat);
+    BNPVI_LAUNCH_CHECK();
+    const int64_t rblocks = ceil_div(a.N, kNormRows);
+    BNPVI_REQUIRE(rblocks <= 65535, "estep: %lld row blocks", (long long)rblocks);
+    dim3 grid((unsigned)ceil_div(Lp, 256), (unsigned)rblocks);
+    if (a.estats) {
+      int rc = a.ctx->slabs.ensure((size_t)rblocks * 2 * L * sizeof(double));
+      if (rc) return rc;
+      double* eslab = (double*)a.ctx->slabs.ptr;
+      hipLaunchKernelGGL(estep_normalize_cols_kernel<true>, grid, dim3(256), 0, a.stream, a.phi, a.logphi,
+                         rowstat, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, eslab);
+      BNPVI_LAUNCH_CHECK();
+      return estep_reduce_slabs(a, eslab, (int)rblocks);
+    }
+    hipLaunchKernelGGL(estep_normalize_cols_kernel<false>, grid, dim3(256), 0, a.stream, a.phi, a.logphi,
+                       rowstat, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, (double*)nullptr);
+    BNPVI_LAUNCH_CHECK();
+    return BNPVI_OK;
+  }
   if (a.estats) BNPVI_HIP(hipMemsetAsync(a.estats, 0, (size_t)2 * L * sizeof(double), a.stream));
   int64_t nb = ceil_div(a.N, 4);
   const int64_t capb = (int64_t)a.ctx->num_cu * 8;

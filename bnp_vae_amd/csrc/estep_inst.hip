@@ -89,24 +89,39 @@ static int run_streamed(const EstepArgs& a) {
   const int tiles = Lp / kLT;
   const int nchunk = (tiles + NT - 1) / NT;
   BNPVI_REQUIRE(nchunk <= 65535, "estep: too many leaf chunks (%d)", nchunk);
-  int rc = a.ctx->part.ensure((size_t)a.N * nchunk * sizeof(float2));
+  // per (row, chunk) partials + one (max, log-sum-exp) per row for the column-window normalise pass
+  int rc = a.ctx->part.ensure(((size_t)a.N * nchunk + (size_t)a.N) * sizeof(float2));
   if (rc) return rc;
   float2* part = (float2*)a.ctx->part.ptr;
   const int64_t ntiles = ceil_div(a.N, kFT);
-  int64_t bx = ceil_div(ntiles, kEWaves);
-  int64_t cap = (int64_t)a.ctx->num_cu * 8 / nchunk;
+  // operands of one chunk staged in LDS when they fit (8 waves share them), else read from L2
+  constexpr int kStagedWaves = 8;
+  const size_t lds = (size_t)NT * (DP / 32) * 2 * 64 * sizeof(f16x8) + (size_t)kLT * NT * sizeof(float);
+  const char* env = getenv("BNPVI_ESTEP_STREAM");                   // development switch: "l2"
+  const bool staged = lds <= (size_t)kMaxLdsBytes && !(env && strcmp(env, "l2") == 0);
+  const int waves = staged ? kStagedWaves : kEWaves;
+  const int per_cu = staged ? (int)((size_t)kMaxLdsBytes / lds) : 8;
+  int64_t bx = ceil_div(ntiles, waves);
+  int64_t cap = (int64_t)a.ctx->num_cu * (per_cu > 8 ? 8 : per_cu) / nchunk;
   if (cap < 1) cap = 1;
   if (bx > cap) bx = cap;
   dim3 grid((unsigned)bx, (unsigned)nchunk);
   const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
-  if (a.mode == BNPVI_ESTEP_HARD)
-    hipLaunchKernelGGL((estep_logits_kernel<DP, NT, true>), grid, dim3(kEWaves * 64), 0, a.stream, a.Z,
-                       a.ldz, a.vid, a.N, a.tree->L, Lp, a.apack, a.aavec, a.a32, a.scal, a.prior,
-                       a.half_sz, a.phi, part, nchunk);
-  else
-    hipLaunchKernelGGL((estep_logits_kernel<DP, NT, false>), grid, dim3(kEWaves * 64), 0, a.stream, a.Z,
-                       a.ldz, a.vid, a.N, a.tree->L, Lp, a.apack, a.aavec, a.a32, a.scal, a.prior,
-                       a.half_sz, a.phi, part, nchunk);
+#define BNPVI_LAUNCH_LOGITS(HARD_, WAVES_, LDS_)                                                           \
+  do {                                                                                                    \
+    auto k = estep_logits_kernel<DP, NT, HARD_, WAVES_>;                                                  \
+    if ((LDS_) > 48 * 1024)                                                                               \
+      BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS_))); \
+    hipLaunchKernelGGL(k, grid, dim3(((WAVES_) > 0 ? (WAVES_) : kEWaves) * 64), (LDS_), a.stream, a.Z, a.ldz, \
+                       a.vid, a.N, a.tree->L, Lp, a.apack, a.aavec, a.a32, a.scal, a.prior, a.half_sz,    \
+                       a.phi, part, nchunk);                                                              \
+  } while (0)
+  if (a.mode == BNPVI_ESTEP_HARD) {
+    if (staged) BNPVI_LAUNCH_LOGITS(true, kStagedWaves, lds); else BNPVI_LAUNCH_LOGITS(true, 0, (size_t)0);
+  } else {
+    if (staged) BNPVI_LAUNCH_LOGITS(false, kStagedWaves, lds); else BNPVI_LAUNCH_LOGITS(false, 0, (size_t)0);
+  }
+#undef BNPVI_LAUNCH_LOGITS
   if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
   BNPVI_LAUNCH_CHECK();
   return estep_finish_streamed(a, part, nchunk);

@@ -590,15 +590,19 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
 // Streamed regime (trees too large for the fused kernel), pass A: raw logits for one 16-frame
 // tile x one chunk of NT 16-leaf tiles, written into phi; part[n][chunk] = (max,
 // sum exp(logit-max)) in soft mode, (max of -d^2, arg-max leaf as float bits) in hard mode.
-// Operands come straight from L2 (the packed image is lane-linear: 1 KiB per wave-load).
+// A workgroup keeps ONE leaf chunk (blockIdx.y) for all its frame tiles.  WAVES > 0: the chunk's
+// packed operands (NT * DP * 64 B, 128 KiB at DP = 256) are staged in LDS once per workgroup and
+// shared by its WAVES waves; WAVES = 0: four waves read them straight from L2 for every tile
+// (kept for operand chunks that do not fit the LDS).
 // ------------------------------------------------------------------------------------------
-template <int DP, int NT, bool HARD>
-__global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
+template <int DP, int NT, bool HARD, int WAVES = 0>
+__global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logits_kernel(
     const float* __restrict__ Z, int ldz, const int32_t* __restrict__ vid, int64_t N, int L, int Lp,
     const f16x8* __restrict__ apack, const float* __restrict__ aavec, const float* __restrict__ a32,
     const float* __restrict__ scal, const float* __restrict__ prior, float half_sz,
     float* __restrict__ phi, float2* __restrict__ part, int nchunk) {
   constexpr int S = DP / 32;
+  constexpr int kWaves = WAVES > 0 ? WAVES : kEWaves;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int j = lane & 15;
@@ -608,11 +612,23 @@ __global__ __launch_bounds__(kEWaves * 64) void estep_logits_kernel(
   int tiles_valid = Lp / kLT - T0;
   tiles_valid = tiles_valid > NT ? NT : tiles_valid;
   const int64_t ntiles = (N + kFT - 1) / kFT;
-  LeafOperands lo_{apack + (int64_t)T0 * S * 2 * 64, aavec + kLT * T0, a32 + (int64_t)kLT * T0 * DP, scal[0],
-                   scal[2]};
+  const f16x8* a_src = apack + (int64_t)T0 * S * 2 * 64;
+  const float* aa_src = aavec + kLT * T0;
+  if constexpr (WAVES > 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                  // [NT*S*2*64]
+    float* aa_lds = reinterpret_cast<float*>(a_lds + NT * S * 2 * 64);  // [16*NT]
+    for (int e = threadIdx.x; e < NT * S * 2 * 64; e += blockDim.x)
+      a_lds[e] = e < tiles_valid * S * 2 * 64 ? a_src[e] : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = threadIdx.x; e < kLT * NT; e += blockDim.x) aa_lds[e] = e < kLT * tiles_valid ? aa_src[e] : 0.f;
+    __syncthreads();
+    a_src = a_lds;
+    aa_src = aa_lds;
+  }
+  LeafOperands lo_{a_src, aa_src, a32 + (int64_t)kLT * T0 * DP, scal[0], scal[2]};
 
-  for (int64_t tile = (int64_t)blockIdx.x * kEWaves + wave; tile < ntiles;
-       tile += (int64_t)gridDim.x * kEWaves) {
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles;
+       tile += (int64_t)gridDim.x * kWaves) {
     const int64_t n = tile * kFT + j;
     const bool ok = n < N;
     const int64_t nn = ok ? n : N - 1;

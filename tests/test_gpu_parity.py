@@ -180,6 +180,7 @@ def _regular_case(N, D, bf, levels, fpv, seed):
     (3000, 64, 8, 3, [100, 57]),      # BASELINE config 3 shape (K=585, L=512): streamed regime
     (2500, 40, 3, 2, [300]),          # D not a kernel width (padded 40 -> 64), L=9
     (4000, 128, 4, 3, [500]),         # reference tree shape, D=128
+    (1500, 200, 7, 3, [300, 77]),     # L=343, D=200 -> 256: streamed regime, 128 KiB operand chunks staged in LDS
 ])
 def test_iteration_against_oracle(N, D, bf, levels, fpv):
     ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=7)
@@ -220,6 +221,8 @@ def test_iteration_against_oracle(N, D, bf, levels, fpv):
     (2100, 64, 9, 2, [64]),           # L=81 (padded 96): last 64-leaf chunk half empty
     (2300, 64, 16, 2, [128, 77]),     # L=256: single-pass variant with 4 chunks, all full
     (1900, 48, 6, 3, [90]),           # L=216 (padded 224), D=48 -> 64: 4 chunks, last one ragged
+    (1300, 200, 7, 3, [256, 33]),     # L=343, D=200 -> 256: operands exceed the LDS -> streamed regime,
+                                      # column-window normalise pass (no arg-max asked)
 ])
 def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
     """Trees with more than 64 leaves take the row kernel (estep_rows.h) when neither hard mode nor
