@@ -330,9 +330,14 @@ int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi,
     return BNPVI_OK;
   }
   if (!want_q) {
-    // default path: LDS-DMA ring (mstep_dma.hip); BNPVI_MSTEP_PATH=reg keeps the register-streamed kernel
+    // default path: LDS-DMA ring (mstep_dma.hip); BNPVI_MSTEP_PATH=reg | dma force the register-streamed / per-wave ring kernels
     const char* force = getenv("BNPVI_MSTEP_PATH");
     if (!(force && strcmp(force, "reg") == 0)) {
+      if (!(force && strcmp(force, "dma") == 0)) {
+        // large trees: workgroup-wide tiles (mstep_wide.hip)
+        const int rc = launch_leaf_stats_wide(ctx, Z, ldz, phi, ldphi, vid, N, D, L, V, stats, mass, s);
+        if (rc != BNPVI_EUNSUPPORTED) return rc;
+      }
       const int rc = launch_leaf_stats_dma(ctx, Z, ldz, phi, ldphi, vid, N, D, L, V, stats, mass, s);
       if (rc != BNPVI_EUNSUPPORTED) return rc;
     }

@@ -72,6 +72,28 @@ __device__ __forceinline__ void mac6(const Frag& ah, const Frag& am, const Frag&
 }
 
 
+// ---- LDS-DMA helpers (mstep_dma.hip, mstep_wide.hip)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void dma16(const void* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, float* l) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left alone): gfx9 encoding
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+
+// wide-tile variant for large trees (mstep_wide.hip); BNPVI_EUNSUPPORTED for shapes it does not cover
+int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
+                           const int32_t* vid, int64_t N, int D, int L, int V, double* stats, double* mass,
+                           hipStream_t s);
+
 // LDS-DMA variant (mstep_dma.hip); returns BNPVI_EUNSUPPORTED for shapes it does not take
 int launch_leaf_stats_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
                           const int32_t* vid, int64_t N, int D, int L, int V, double* stats, double* mass,

@@ -19,22 +19,6 @@ namespace bnpvi {
 
 constexpr int kDmaWaves = 4;
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__device__ __forceinline__ void dma16(const void* g, float* l) {
-  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
-}
-__device__ __forceinline__ void dma4(const void* g, float* l) {
-  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0);
-}
-
-// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt left alone): gfx9 encoding
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-}
-
 template <int TL, int TD>
 struct DmaSlot {
   static constexpr int kA = kKStep * TL * 32;          // floats of the phi block

@@ -181,6 +181,8 @@ def _regular_case(N, D, bf, levels, fpv, seed):
     (2500, 40, 3, 2, [300]),          # D not a kernel width (padded 40 -> 64), L=9
     (4000, 128, 4, 3, [500]),         # reference tree shape, D=128
     (1500, 200, 7, 3, [300, 77]),     # L=343, D=200 -> 256: streamed regime, 128 KiB operand chunks staged in LDS
+    (1501, 128, 4, 5, [256, 100]),    # L=1024, D=128: workgroup-wide M-step tiles (mstep_wide.hip), ragged N
+    (700, 130, 6, 4, [512]),          # L=1296 (5.06 leaf blocks of 256), D=130 -> 256: partial last leaf block
 ])
 def test_iteration_against_oracle(N, D, bf, levels, fpv):
     ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=7)
