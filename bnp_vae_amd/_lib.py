@@ -65,6 +65,7 @@ EXPORTS = {
     "bnpvi_params_prior": (_i, [_p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p, _i, _d, _p, _p, _p]),
     "bnpvi_estep": (_i, [_p, _p, _p, _i, _p, _i64, _i, _p, _p, _d, _i, _p, _p, _p, _p, _p]),
     "bnpvi_kmeans_pass": (_i, [_p, _p, _i, _i64, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+    "bnpvi_path_distances": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _p]),
     "bnpvi_remap_columns": (_i, [_p, _p, _i, _p, _i, _i64, _i, _p, _p, _p]),
 }
 

@@ -370,6 +370,24 @@ int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D,
                             best_score, (hipStream_t)stream);
 }
 
+int bnpvi_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz, int64_t N, int D,
+                         const double* alpha, const int32_t* assign, int max_depth, int32_t* node_out,
+                         double* dist_out, void* stream) {
+  int rc = check_common("bnpvi_path_distances", ctx, N, D, ldz);
+  if (rc) return rc;
+  BNPVI_REQUIRE(tree && Z && alpha && assign && node_out && dist_out, "bnpvi_path_distances: NULL argument");
+  int deepest = 0;
+  for (int l = 0; l < tree->L; ++l) {
+    const int d = tree->depth[tree->node_of_leaf[l]];
+    deepest = d > deepest ? d : deepest;
+  }
+  BNPVI_REQUIRE(N >= 1 && max_depth >= deepest + 1 && max_depth <= 64,
+                "bnpvi_path_distances: max_depth=%d, the deepest leaf needs %d (at most 64)", max_depth,
+                deepest + 1);
+  return launch_path_distances(ctx, tree, Z, ldz, N, D, alpha, assign, max_depth, node_out, dist_out,
+                               (hipStream_t)stream);
+}
+
 int bnpvi_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out, int ld_out,
                         int64_t N, int Lnew, const int32_t* src_host, const float* scale_host,
                         void* stream) {

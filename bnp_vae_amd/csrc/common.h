@@ -133,6 +133,9 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
                  double sZ, int mode, float* phi, float* logphi, int32_t* assign,
                  double* estats, hipStream_t s);
 
+int launch_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz, int64_t N, int D,
+                          const double* alpha, const int32_t* assign, int max_depth, int32_t* node_out,
+                          double* dist_out, hipStream_t s);
 int launch_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D,
                        const float* w, int ldw, const float* center, int first, float* dist2,
                        int64_t* best_row, float* best_score, hipStream_t s);

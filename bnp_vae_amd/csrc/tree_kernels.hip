@@ -977,6 +977,54 @@ __global__ __launch_bounds__(1024) void slab_reduce_kernel(const double* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// ||alpha_k - z_n||_2 for the nodes k on the root -> leaf path of frame n (the ranking key of
+// src/create_hierarchy.py:50-51).  One wave per frame: walk up from the assigned leaf, lanes
+// over the dimensions, fp64 sums of fp64 differences (the reference is NumPy fp64).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void path_distances_kernel(
+    const float* __restrict__ Z, int ldz, int64_t N, int D, const double* __restrict__ alpha,
+    const int32_t* __restrict__ assign, const int32_t* __restrict__ node_of_leaf,
+    const int32_t* __restrict__ parent, const int32_t* __restrict__ depth, int L, int max_depth,
+    int32_t* __restrict__ node_out, double* __restrict__ dist_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  int leaf = assign[n];
+  leaf = leaf < 0 ? 0 : (leaf >= L ? L - 1 : leaf);
+  int k = node_of_leaf[leaf];
+  const int dleaf = depth[k];
+  for (int j = lane; j < max_depth; j += 64)
+    if (j > dleaf) {
+      node_out[n * max_depth + j] = -1;
+      dist_out[n * max_depth + j] = 0.0;
+    }
+  for (int j = dleaf; j >= 0 && k >= 0; --j) {
+    double acc = 0.0;
+    for (int d = lane; d < D; d += 64) {
+      const double df = alpha[(int64_t)k * D + d] - (double)Z[n * ldz + d];
+      acc = fma(df, df, acc);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0 && j < max_depth) {
+      node_out[n * max_depth + j] = k;
+      dist_out[n * max_depth + j] = sqrt(acc);
+    }
+    k = parent[k];
+  }
+}
+
+int launch_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz, int64_t N, int D,
+                          const double* alpha, const int32_t* assign, int max_depth, int32_t* node_out,
+                          double* dist_out, hipStream_t s) {
+  (void)ctx;
+  hipLaunchKernelGGL(path_distances_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, s, Z, ldz, N, D, alpha,
+                     assign, t->d_node_of_leaf, t->d_parent, t->d_depth, t->L, max_depth, node_out, dist_out);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
 int launch_slab_reduce(const double* slab, int nslab, int64_t elems, double* out, hipStream_t s) {
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)ceil_div(elems, 32)), dim3(1024), 0, s, slab,
                      nslab, elems, out);

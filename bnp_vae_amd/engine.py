@@ -42,6 +42,9 @@ class FlatTree(object):
         self.Lp = _lib.padded_leaves(self.L)
         self.node_of_leaf = np.zeros(self.L, dtype=np.int32)
         check(lib.bnpvi_tree_leaf_nodes(h, self.node_of_leaf.ctypes.data_as(C.c_void_p)))
+        self.depth = np.zeros(self.K, dtype=np.int32)          # pre-order: a parent precedes its children
+        for k in range(1, self.K):
+            self.depth[k] = self.depth[self.parent[k]] + 1
 
     def close(self):
         if self.handle is not None:
@@ -240,6 +243,19 @@ class DeviceVI(object):
                               _ptr(self.estats if want_stats else None), self._stream()),
               "bnpvi_estep")
         return logphi, assign
+
+    def path_distances(self, assign, max_depth=None):
+        """||alpha_k - z_n|| (fp64) for the nodes k on the root -> leaf path of every frame's
+        assigned leaf (src/create_hierarchy.py:50): (node [N, max_depth] int32, -1 below the
+        leaf; dist [N, max_depth] float64)."""
+        if max_depth is None:
+            max_depth = int(self.tree.depth.max()) + 1
+        node = self._empty((self.N, max_depth), torch.int32)
+        dist = self._empty((self.N, max_depth), torch.float64)
+        check(lib.bnpvi_path_distances(self.ctx, self.tree.handle, _ptr(self.Z), self.Dp, self.N, self.D,
+                                       _ptr(self.alpha), _ptr(assign), int(max_depth), _ptr(node), _ptr(dist),
+                                       self._stream()), "bnpvi_path_distances")
+        return node, dist
 
     def allreduce_estats(self):
         vdist.allreduce_sum_(self.estats, self.group)

@@ -170,6 +170,20 @@ int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z_dev, int ldz, int64_t N, in
                       float* dist2_dev, int64_t* best_row_dev, float* best_score_dev,
                       void* stream);
 
+/* ---- distances of every frame to the nodes on the path of its leaf ---------------------------
+ * The per-node ranking of src/create_hierarchy.py:40-53 ("top-K closest frames" of a node among
+ * the frames assigned to the leaves below it) and the nearest-leaf distance of
+ * src/compute_acc_frame_avg_dynamic.py:49-52 need ||alpha_k - z_n||_2 for the nodes k on the
+ * root -> leaf path of frame n only.  assign_dev[N] = DFS leaf index of each frame (the arg-min
+ * output of bnpvi_estep in HARD mode).  For j < max_depth:
+ *   node_dev[n*max_depth + j] = pre-order index of the path node at depth j (root = depth 0),
+ *                               -1 below the leaf;
+ *   dist_dev[n*max_depth + j] = ||alpha_node - z_n||_2 in fp64 (direct differences), 0 where -1.
+ * max_depth must cover the deepest leaf (depth + 1 entries). */
+int bnpvi_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int ldz,
+                         int64_t N, int D, const double* alpha_dev, const int32_t* assign_dev,
+                         int max_depth, int32_t* node_dev, double* dist_dev, void* stream);
+
 /* ---- column surgery for split / merge: src/var_inf.py:196,232 ---------------------------
  * out[n][j] = scale_host[j] * in[n][src_host[j]]  for j < Lnew; padded columns = 0.
  * split: children take phi_parent/num_splits; merge: pruned leaves' columns are dropped

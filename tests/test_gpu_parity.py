@@ -391,6 +391,34 @@ def test_mstep_bit_reproducible_behind_the_estep():
     dev.close()
 
 
+def test_closest_frames_per_node_against_oracle():
+    """bnp_vae_amd.hierarchy.closest_frames (hard E-step + path-distance kernel + stable device
+    sort) against the restatement of src/create_hierarchy.py:40-53,82-91 on a tree grown by
+    split / merge, with duplicated frames so that the stable tie order matters."""
+    from bnp_vae_amd.hierarchy import closest_frames
+    from oracle.hierarchy_oracle import closest_frames as oracle_closest, dfs_leaves
+    g = load("traj_dynamic.npz")
+    m = meta(g)
+    vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    np.random.seed(13)
+    for e in range(3):
+        vi.update_variational_parameters(make_latent_dict(g['Z%d' % e], list(g['fpv'])))
+    nodes = vi.get_nodes_list(vi.root, [])
+    Z = np.asarray(g['Z2'], dtype=np.float32)
+    z = np.concatenate([Z, Z[:40], Z[5:25]]).astype(np.float32)       # exact duplicates: distance ties
+    for K in (1, 4, 1000):
+        assign, top = closest_frames(nodes, z, K)
+        want_assign, want_top = oracle_closest(vi.root, z.astype(np.float64), K)
+        d = np.linalg.norm(np.asarray([l.alpha for l in dfs_leaves(vi.root)])[None] - z[:, None].astype(np.float64), axis=2)
+        for i in np.nonzero(assign != want_assign)[0]:                  # near-ties of the two nearest leaves only
+            assert abs(d[i, assign[i]] - d[i, want_assign[i]]) < 1e-5
+        if np.array_equal(assign, want_assign):
+            assert set(id(n) for n in top) == set(id(n) for n in want_top)
+            for n in want_top:
+                assert top[n] == want_top[n], n.node_id
+    assert sum(len(v) for v in top.values()) >= len(z)                  # K=1000: every frame under its leaf
+
+
 def test_matrix_entry_point_matches_dict_entry_point():
     """update_variational_parameters_matrix (NumPy matrix, device tensor) walks the same
     trajectory -- splits and merges included -- as the reference-shaped dict entry point."""

@@ -115,3 +115,22 @@ def test_weighted_kmeans_golden():
     for i in range(3):
         c = OracleVarInf.weighted_kmeans(g['data%d' % i], g['w%d' % i], int(g['K%d' % i]))
         np.testing.assert_allclose(c, g['centers%d' % i], rtol=0, atol=0)
+
+
+def test_hierarchy_oracle_hand_case():
+    """oracle/hierarchy_oracle.py (restating src/create_hierarchy.py:40-53,82-91) on a case small
+    enough to do by hand: two leaves at (1,0) and (-1,0) under a root at the origin."""
+    from oracle.hierarchy_oracle import closest_frames
+
+    class N(object):
+        def __init__(self, alpha, parent, leaf):
+            self.alpha, self.parent, self.isLeafNode, self.children = np.asarray(alpha, float), parent, leaf, []
+            if parent is not None:
+                parent.children.append(self)
+
+    root = N([0, 0], None, False)
+    a, b = N([1, 0], root, True), N([-1, 0], root, True)
+    z = np.asarray([[0.9, 0], [2, 0], [-0.5, 0], [-3, 0], [0.2, 0]])
+    assign, top = closest_frames(root, z, 2)
+    assert list(assign) == [0, 0, 1, 1, 0]
+    assert top[a] == [0, 4] and top[b] == [2, 3] and top[root] == [4, 2]
