@@ -78,3 +78,65 @@ def closest_frames(nodes_list, z, K, device=None):
         return assign.cpu().numpy().astype(np.int64), result
     finally:
         dev.close()
+
+
+def nearest_leaf(nodes_list, z, device=None):
+    """(N,) index of the nearest leaf (leaves depth-first) of every row of z:
+    src/compute_acc_frame_avg_dynamic.py:49-52 / :127-128 on the device (hard-mode E-step)."""
+    from . import _lib
+    from .engine import DeviceVI
+    order, parent, is_leaf, alpha = _flatten(nodes_list)
+    dev = DeviceVI(device=device)
+    try:
+        N = int(z.shape[0])
+        dev.set_latents(z, np.zeros(N, dtype=np.int32), 1)
+        dev.set_tree(parent, is_leaf, alpha, np.ones(len(order)))
+        _, assign = dev.estep(mode=_lib.ESTEP_HARD, want_assign=True, want_stats=False)
+        return assign.cpu().numpy().astype(np.int64)
+    finally:
+        dev.close()
+
+
+def class_vote(nodes_list, z_train, train_labels, z_test, decay_factor=0.0, device=None):
+    """Tree-decayed class vote of src/compute_acc_frame_avg_dynamic.py:49-129.
+
+    Frames vote for the class of their nearest leaf (:61-63); votes are summed up the tree
+    (:66-82); a leaf's score is its own votes plus decay_factor^j times the votes of its j-th
+    ancestor (:89-108); leaves without any score borrow the class of the nearest leaf (by alpha)
+    that has one (:114-122); test frames get the class of their nearest leaf (:124-129).
+    train_labels: (N,) integer classes 0..C-1.  Returns (path2class [L], predicted [N_test]);
+    leaves are numbered depth-first.  The O(N) parts (both nearest-leaf passes, the vote
+    histogram) run on the device, the O(L*C) tree arithmetic on the host."""
+    import torch
+    order, parent, is_leaf, alpha = _flatten(nodes_list)
+    leaves = [k for k in range(len(order)) if is_leaf[k]]
+    L = len(leaves)
+    labels = np.asarray(train_labels).astype(np.int64)
+    C = len(np.unique(labels))                                          # :47
+    assign = nearest_leaf(nodes_list, z_train, device)
+    flat = torch.from_numpy(assign * C + labels)
+    counts = torch.bincount(flat, minlength=L * C).numpy().reshape(L, C).astype(np.float64)
+    cumulative = np.zeros((len(order), C))
+    for j, k in enumerate(leaves):
+        cumulative[k] = counts[j]
+    for k in range(len(order) - 1, 0, -1):                              # pre-order: children after parents
+        cumulative[parent[k]] += cumulative[k]
+    total = np.zeros((L, C))
+    for j, k in enumerate(leaves):
+        mult, a = 1.0, k
+        while a >= 0:
+            total[j] += mult * cumulative[a]
+            a = parent[a]
+            mult *= decay_factor
+    path2class = np.argmax(total, axis=1)
+    leaf_alpha = alpha[leaves]
+    for j in range(L):
+        if np.max(total[j]) == 0:
+            dist = np.linalg.norm(leaf_alpha[j] - leaf_alpha, axis=1)
+            m = int(np.argmin(dist))
+            while np.max(total[m]) == 0:
+                dist[m] = np.inf
+                m = int(np.argmin(dist))
+            path2class[j] = path2class[m]
+    predicted = path2class[nearest_leaf(nodes_list, z_test, device)]
+    return path2class, predicted

@@ -51,3 +51,54 @@ def closest_frames(root, z, K):
 
     rec(root)
     return path_assignments, top
+
+
+def get_internal_nodes(node, result):                                # src/create_hierarchy.py:21-28, same in
+    if not node.isLeafNode:                                           # compute_acc_frame_avg_dynamic.py
+        result.append(node)
+        for c in node.children:
+            result = get_internal_nodes(c, result)
+    return result
+
+
+def class_vote(root, z_train, train_labels, z_test, decay_factor=0.0):
+    """src/compute_acc_frame_avg_dynamic.py:41-129 with the reference's index bookkeeping
+    (internal nodes first, then leaves; parents found by node_id lookups)."""
+    leaf_nodes_list = dfs_leaves(root)
+    alpha_values = np.asarray([l.alpha for l in leaf_nodes_list])
+    num_paths = len(leaf_nodes_list)
+    train_labels = np.asarray(train_labels)
+    num_classes = len(np.unique(train_labels))
+    path_assignments = [int(np.argmin(np.linalg.norm(alpha_values - z, axis=1))) for z in z_train]
+    counts = np.zeros(shape=(num_paths, num_classes))
+    for i, l in enumerate(path_assignments):
+        counts[l][int(train_labels[i])] += 1
+    internal_nodes_list = get_internal_nodes(root, [])
+    num_internal_nodes = len(internal_nodes_list)
+    counts_cumulative = np.concatenate((np.zeros(shape=(num_internal_nodes, num_classes)), counts.copy()), axis=0)
+    leaf_ids = [x.node_id for x in leaf_nodes_list]
+    internal_ids = [x.node_id for x in internal_nodes_list]
+    for i, node in reversed(list(enumerate(internal_nodes_list))):
+        for c in node.children:
+            idx = num_internal_nodes + leaf_ids.index(c.node_id) if c.isLeafNode else internal_ids.index(c.node_id)
+            counts_cumulative[i] += counts_cumulative[idx]
+    counts_total = np.zeros(shape=(num_paths, num_classes))
+    for i in range(num_paths):
+        j = i + num_internal_nodes
+        mult = 1.0
+        while j >= 0:
+            counts_total[i] += mult * counts_cumulative[j, :]
+            node = leaf_nodes_list[j - num_internal_nodes] if j >= num_internal_nodes else internal_nodes_list[j]
+            j = internal_ids.index(node.parent.node_id) if node.parent is not None else -1
+            mult *= decay_factor
+    path2class = np.argmax(counts_total, axis=1)
+    for i in range(len(path2class)):
+        if np.max(counts_total[i]) == 0:
+            dist = np.linalg.norm(alpha_values[i] - alpha_values, axis=1)
+            min_idx = np.argmin(dist)
+            while np.max(counts_total[min_idx]) == 0:
+                dist[min_idx] = np.inf
+                min_idx = np.argmin(dist)
+            path2class[i] = path2class[min_idx]
+    predicted = [path2class[int(np.argmin(np.linalg.norm(alpha_values - z, axis=1)))] for z in z_test]
+    return path2class, np.asarray(predicted)

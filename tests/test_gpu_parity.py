@@ -419,6 +419,29 @@ def test_closest_frames_per_node_against_oracle():
     assert sum(len(v) for v in top.values()) >= len(z)                  # K=1000: every frame under its leaf
 
 
+@pytest.mark.parametrize("decay", [0.0, 0.5])
+def test_class_vote_against_oracle(decay):
+    """hierarchy.class_vote (nearest-leaf passes and vote histogram on the device) against the
+    restatement of src/compute_acc_frame_avg_dynamic.py:41-129, on a split/merged tree; with
+    decay 0 some leaves get no vote and borrow a neighbour's class."""
+    from bnp_vae_amd.hierarchy import class_vote
+    from oracle.hierarchy_oracle import class_vote as oracle_vote
+    g = load("traj_dynamic.npz")
+    m = meta(g)
+    vi = make_vi(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    np.random.seed(13)
+    for e in range(3):
+        vi.update_variational_parameters(make_latent_dict(g['Z%d' % e], list(g['fpv'])))
+    nodes = vi.get_nodes_list(vi.root, [])
+    z_train = np.asarray(g['Z2'], dtype=np.float32)[:60]                # few frames: some leaves stay empty
+    z_test = np.asarray(g['Z3'], dtype=np.float32)
+    labels = np.random.RandomState(3).randint(0, 4, size=len(z_train))
+    p2c, pred = class_vote(nodes, z_train, labels, z_test, decay_factor=decay)
+    want_p2c, want_pred = oracle_vote(vi.root, z_train.astype(np.float64), labels, z_test.astype(np.float64), decay)
+    np.testing.assert_array_equal(p2c, want_p2c)
+    assert (pred != want_pred).mean() <= 0.01                           # nearest-leaf near-ties only
+
+
 def test_matrix_entry_point_matches_dict_entry_point():
     """update_variational_parameters_matrix (NumPy matrix, device tensor) walks the same
     trajectory -- splits and merges included -- as the reference-shaped dict entry point."""

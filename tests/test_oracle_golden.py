@@ -134,3 +134,24 @@ def test_hierarchy_oracle_hand_case():
     assign, top = closest_frames(root, z, 2)
     assert list(assign) == [0, 0, 1, 1, 0]
     assert top[a] == [0, 4] and top[b] == [2, 3] and top[root] == [4, 2]
+
+
+def test_class_vote_oracle_hand_case():
+    """oracle/hierarchy_oracle.class_vote (src/compute_acc_frame_avg_dynamic.py:41-129) by hand:
+    leaf (5,0) gets no vote and borrows the class of its nearest voted neighbour (1,0)."""
+    from oracle.hierarchy_oracle import class_vote
+
+    class N(object):
+        def __init__(self, node_id, alpha, parent, leaf):
+            self.node_id, self.alpha, self.parent = node_id, np.asarray(alpha, float), parent
+            self.isLeafNode, self.children = leaf, []
+            if parent is not None:
+                parent.children.append(self)
+
+    r = N('0', [0, 0], None, False)
+    N('0-0', [1, 0], r, True); N('0-1', [-1, 0], r, True); N('0-2', [5, 0], r, True)
+    z = np.asarray([[0.9, 0], [2, 0], [-0.5, 0], [-3, 0], [0.2, 0]])
+    p2c, pred = class_vote(r, z, [0, 0, 1, 1, 0], np.asarray([[4.0, 0], [-2, 0]]), 0.0)
+    assert list(p2c) == [0, 1, 0] and list(pred) == [0, 1]
+    p2c, _ = class_vote(r, z, [0, 0, 1, 1, 0], z[:1], 1.0)        # decay 1: every leaf sees all 5 votes (3 x class 0)
+    assert list(p2c) == [0, 0, 0]
