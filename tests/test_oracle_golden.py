@@ -153,5 +153,5 @@ def test_class_vote_oracle_hand_case():
     z = np.asarray([[0.9, 0], [2, 0], [-0.5, 0], [-3, 0], [0.2, 0]])
     p2c, pred = class_vote(r, z, [0, 0, 1, 1, 0], np.asarray([[4.0, 0], [-2, 0]]), 0.0)
     assert list(p2c) == [0, 1, 0] and list(pred) == [0, 1]
-    p2c, _ = class_vote(r, z, [0, 0, 1, 1, 0], z[:1], 1.0)        # decay 1: every leaf sees all 5 votes (3 x class 0)
-    assert list(p2c) == [0, 0, 0]
+    p2c, _ = class_vote(r, z, [0, 0, 1, 1, 0], z[:1], 1.0)        # decay 1: own votes + all 5 votes of the root:
+    assert list(p2c) == [0, 1, 0]                                 # (6,2), (3,4), (3,2)
