@@ -577,21 +577,33 @@ __device__ __forceinline__ void params_operands_lds_block(const MidArgs& a, char
   // ---- leaf operands of the E-step from the LDS copy (layout: leaf_operands_block)
   const int DP = a.DP, Lp = a.LpPack;
   const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  // fp32 rows for the E-step's exact-recompute path: coalesced
+  for (int e = tid; e < Lp * DP; e += T) {
+    const int leaf = e / DP, d = e % DP;
+    a.a32[e] = (leaf < L && d < D) ? (float)al[node_of_leaf[leaf] * D + d] : 0.f;
+  }
+  // ||alpha||^2 and max|alpha|: ONE THREAD per leaf walking its row in LDS (a wave per leaf with
+  // a 6-step fp64 shuffle reduction per row was the longest phase of this workgroup); the walk
+  // starts at a lane-dependent dimension so that the lanes of a wave hit different banks
   float amax = 0.f, aamax = 0.f;
-  for (int leaf = wave; leaf < Lp; leaf += nw) {
-    const double* row = leaf < L ? al + node_of_leaf[leaf] * D : nullptr;
+  for (int leaf = tid; leaf < Lp; leaf += T) {
     double aa = 0.0;
-    for (int d = lane; d < DP; d += 64) {
-      const float f = (row && d < D) ? (float)row[d] : 0.f;
-      a.a32[(int64_t)leaf * DP + d] = f;
-      aa += (double)f * (double)f;
-      amax = fmaxf(amax, fabsf(f));
+    if (leaf < L) {
+      const double* row = al + node_of_leaf[leaf] * D;
+      const int start = lane % D;
+      for (int q = 0; q < D; ++q) {
+        int d = start + q;
+        d = d >= D ? d - D : d;
+        const float f = (float)row[d];
+        aa = fma((double)f, (double)f, aa);
+        amax = fmaxf(amax, fabsf(f));
+      }
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) aa += __shfl_xor(aa, off);
-    if (lane == 0) a.aavec[leaf] = (float)aa;
+    a.aavec[leaf] = (float)aa;
     aamax = fmaxf(aamax, (float)aa);
   }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) aamax = fmaxf(aamax, __shfl_xor(aamax, off));
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
   if (lane == 0) {
