@@ -212,10 +212,20 @@ __device__ double digamma_pos(double x) {
 #ifdef BNPVI_TABLATE_NODIGAMMA
   return x * 0.5;
 #endif
+  // x < 10: shift by 9 with ONE reciprocal, sum_{i<9} 1/(x+i) = P'(x)/P(x) for P = prod (x+i)
+  // (a loop of up to nine reciprocals, run to the longest trip count in the wave, was a third of
+  // the stick chain's time)
   double r = 0.0;
-  while (x < 10.0) {
-    r -= recip_pos(x);
-    x += 1.0;
+  if (x < 10.0) {
+    double p = x, dp = 1.0;
+#pragma unroll
+    for (int i = 1; i < 9; ++i) {
+      const double f = x + (double)i;
+      dp = fma(dp, f, p);
+      p *= f;
+    }
+    r = -dp * recip_pos(p);
+    x += 9.0;
   }
   const double rx = recip_pos(x);
   const double f = rx * rx;
@@ -464,6 +474,7 @@ struct MidArgs {
   float* prior;
   // leaf operands
   int DP, LpPack;
+  int stick_waves;         // waves per stick workgroup that take a video (LDS: L + 2K doubles each)
   int block0_lds;          // workgroup 0 keeps alpha and the tree in LDS (it fits)
   float* a32;
   float* aavec;
@@ -664,8 +675,9 @@ __global__ __launch_bounds__(kMidWaves * 64) void midstep_small_kernel(MidArgs a
   }
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  if (wave >= a.stick_waves) return;
   double* Pm = reinterpret_cast<double*>(smem_raw) + (size_t)wave * (a.L + 2 * a.K);
-  const int v = (blockIdx.x - 1) * kMidWaves + wave;
+  const int v = (blockIdx.x - 1) * a.stick_waves + wave;
   if (v >= a.V) return;
   stick_wave_video<true, true, true>(v, lane, Pm, Pm + a.L, Pm + a.L + a.K, a.mass, a.mass, a.gamma, nullptr,
                                      a.stats, a.W, a.sB, a.sZ, a.parent, a.node_of_leaf, a.leaf_lo, a.leaf_hi,
@@ -676,8 +688,12 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
                         double sZ, const double* alpha0, double* alpha, double* sigma, double* mass, int V,
                         double gamma_hyper, double* gamma, float* prior, hipStream_t s) {
   const int DP = bnpvi_padded_dim(D);
-  size_t lds = (size_t)kMidWaves * (t->L + 2 * t->K) * sizeof(double);
-  const bool small = (int64_t)t->K * D <= 64 * 1024 && lds <= 64 * 1024 &&
+  // stick workgroups: as many of the 16 waves take a video as fit 64 KB of LDS (L + 2K doubles each)
+  const size_t per_wave = (size_t)(t->L + 2 * t->K) * sizeof(double);
+  int stick_waves = (int)((size_t)64 * 1024 / per_wave);
+  stick_waves = stick_waves > kMidWaves ? kMidWaves : stick_waves;
+  size_t lds = (size_t)stick_waves * per_wave;
+  const bool small = (int64_t)t->K * D <= 64 * 1024 && stick_waves >= 1 && t->K <= kWaveStickMaxK &&
                      (int64_t)round_up(t->Lp, kLT * kStreamNT) * DP <= 64 * 1024;
   ctx->ops_tree = nullptr;
   if (!small) {
@@ -695,6 +711,7 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
   a.nlevels = t->nlevels; a.K = t->K; a.L = t->L; a.Lp = t->Lp;
   a.stats = stats; a.W = W; a.D = D; a.sB = sB; a.sZ = sZ; a.alpha0 = alpha0; a.alpha = alpha; a.sigma = sigma;
   a.mass = mass; a.V = V; a.gamma_hyper = gamma_hyper; a.gamma = gamma; a.prior = prior;
+  a.stick_waves = stick_waves;
   a.DP = DP; a.LpPack = w.LpPack; a.a32 = w.a32; a.aavec = w.aavec; a.apack = w.apack; a.scal = w.scal;
   const size_t lds0 = midstep_block0_lds(t->K, t->L, D, t->nlevels);
   a.block0_lds = lds0 <= kMidBlock0LdsMax && t->nlevels < kMidWaves * 64;
@@ -702,7 +719,7 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)midstep_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
-  hipLaunchKernelGGL(midstep_small_kernel, dim3(1 + (unsigned)ceil_div(V, kMidWaves)), dim3(kMidWaves * 64), lds,
+  hipLaunchKernelGGL(midstep_small_kernel, dim3(1 + (unsigned)ceil_div(V, stick_waves)), dim3(kMidWaves * 64), lds,
                      s, a);
   BNPVI_LAUNCH_CHECK();
   ctx->ops_tree = t;
