@@ -248,11 +248,7 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
   //      memory is free now
   __syncthreads();
   double* acc_lds = reinterpret_cast<double*>(smem_raw);          // [TL*TD][16][64]
-#ifdef BNPVI_S0_OUTSIDE_RING
-  double* s0_lds = reinterpret_cast<double*>(smem_raw + (size_t)kDmaWaves * R * Slot::kFloats * sizeof(float));
-#else
   double* s0_lds = acc_lds + TL * TD * 16 * 64;                   // [TL][32]
-#endif
   for (int w = 0; w < kDmaWaves; ++w) {
     if (wave == w) {
 #pragma unroll
@@ -304,9 +300,6 @@ static int run_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, in
   using Slot = DmaSlot<TL, TD>;
   const int gy = tilesL / TL, gz = tilesD / TD;
   size_t lds = (size_t)kDmaWaves * R * Slot::kFloats * sizeof(float);
-#ifdef BNPVI_S0_OUTSIDE_RING
-  lds += TL * 32 * sizeof(double);
-#endif
   const size_t comb = (size_t)(TL * TD * 16 * 64 + TL * 32) * sizeof(double);
   if (lds < comb) lds = comb;
   int per_cu = (int)((size_t)kMaxLdsBytes / lds);
