@@ -442,6 +442,37 @@ def test_class_vote_against_oracle(decay):
     assert (pred != want_pred).mean() <= 0.01                           # nearest-leaf near-ties only
 
 
+@pytest.mark.parametrize("cfg,N", [("config2", 262_144), ("config3", 65_536)])
+def test_estep_bit_reproducible(cfg, N):
+    """300 E-steps on fixed parameters: phi must come out bit-identical every time (fused kernel
+    for config 2, two-pass row kernel for config 3), the statistics to fp32-atomic-order accuracy."""
+    import torch
+    from bench import CONFIGS, regular_tree, make_latents
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    _n, D, bf, levels = CONFIGS[cfg]
+    parent, is_leaf = regular_tree(bf, levels)
+    K, L = len(parent), int(is_leaf.sum())
+    dev = DeviceVI(device=0)
+    Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, D)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    for _ in range(2):
+        dev.iteration(want_estats=True)
+    first, est0, differ = None, None, 0
+    for _ in range(300):
+        dev.estep(want_stats=True)
+        if first is None:
+            first, est0 = dev.phi.clone(), dev.estats.clone()
+        else:
+            differ += int(not torch.equal(dev.phi, first))
+            assert float(((dev.estats - est0).abs() / (est0.abs() + 1.0)).max()) < 1e-5
+    assert differ == 0
+    dev.close()
+
+
 def test_matrix_entry_point_matches_dict_entry_point():
     """update_variational_parameters_matrix (NumPy matrix, device tensor) walks the same
     trajectory -- splits and merges included -- as the reference-shaped dict entry point."""
