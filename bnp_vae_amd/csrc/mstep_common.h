@@ -49,6 +49,25 @@ __device__ __forceinline__ void split3(const float (&x)[8], Frag& h, Frag& m, Fr
   }
 }
 
+// the same split for one pair of elements -> dword q of the three fragments
+__device__ __forceinline__ void split_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+#ifdef BNPVI_MABLATE_NOSPLIT
+  h = __float_as_uint(x0);
+  m = __float_as_uint(x1);
+  l = __float_as_uint(x0);
+  return;
+#endif
+  const uint32_t u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+  const float r0 = x0 - __uint_as_float(u0 & 0xffff0000u);
+  const float r1 = x1 - __uint_as_float(u1 & 0xffff0000u);
+  const uint32_t v0 = __float_as_uint(r0), v1 = __float_as_uint(r1);
+  const float s0 = r0 - __uint_as_float(v0 & 0xffff0000u);
+  const float s1 = r1 - __uint_as_float(v1 & 0xffff0000u);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
 template <int TL, int TD>
 struct RawStep {
   float a[TL][8];     // phi[frame 8h+e][leaf column of tile a]
@@ -71,6 +90,19 @@ __device__ __forceinline__ void mac6(const Frag& ah, const Frag& am, const Frag&
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc, 0, 0, 0);
 }
 
+// product k (0..5) of mac6, same order
+__device__ __forceinline__ void mac1(int k, const Frag& ah, const Frag& am, const Frag& al, const Frag& bh,
+                                     const Frag& bm, const Frag& bl, f32x16& acc) {
+#ifdef BNPVI_MABLATE_NOMFMA
+  if (k == 0)
+    acc[0] += __uint_as_float((ah.u[0] ^ bl.u[1] ^ am.u[2] ^ bm.u[3] ^ al.u[0] ^ bh.u[1] ^ ah.u[3] ^ bh.u[2] ^
+                               am.u[1] ^ bm.u[0] ^ al.u[2] ^ bl.u[3]) & 0x3fffffffu);
+  return;
+#endif
+  const Frag& a = (k == 0) ? al : (k == 2 || k == 3) ? am : ah;
+  const Frag& b = (k == 0 || k == 3 || k == 5) ? bh : (k == 1) ? bl : bm;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
 
 // ---- LDS-DMA helpers (mstep_dma.hip, mstep_wide.hip)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

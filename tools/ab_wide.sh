@@ -1,0 +1,5 @@
+set -e
+for v in OLDWIDE WNOMFMA WNOSPLIT ""; do
+  if [ -n "$v" ]; then export BNPVI_LIB=$PWD/bnp_vae_amd/variants/libbnpvi_$v.so; else unset BNPVI_LIB; fi
+  timeout -k 10 120 python tools/kbench.py --n 131072 --d 256 --bf 6 --levels 5 --iters 5 --only leaf_stats --tag "v=$v"
+done
