@@ -4,11 +4,17 @@
 //
 // With many (leaf block, dim block) pairs the per-wave ring of mstep_dma.hip re-reads every Z
 // block once per leaf block and every phi block once per dim block through L2 (config 4: 48 GB
-// of L2 traffic for 4 GB of HBM traffic -- L2-bandwidth bound).  Here a workgroup of 8 waves
-// owns a tile of (64 LBW leaves) x (64 DBW dims) over one chunk of frames; the 16 frames of a
-// k-step -- phi block [16][64 LBW], Z block [16][64 DBW], 16 video ids -- are brought into ONE
-// LDS slot by all waves together (LDS-DMA, 1 KiB per instruction, whole row segments) and every
-// wave takes its 64 x 64 sub-tile from it.  L2 traffic drops by LBW for Z and DBW for phi.
+// of L2 traffic for 4 GB of HBM traffic -- L2-bandwidth bound).  Here a workgroup of 4 waves
+// (ONE per SIMD, 512 registers each) owns a tile of (128 LBW leaves) x (128 DBW dims) over one
+// chunk of frames; the 16 frames of a k-step -- phi block [16][128 LBW], Z block [16][128 DBW],
+// 16 video ids -- are brought into ONE LDS slot by all waves together (LDS-DMA, 1 KiB per
+// instruction, whole row segments) and every wave takes its 128 x 128 sub-tile from it.
+//
+// Why 128 x 128 per wave: the bf16 split costs ~5.5 VALU operations per operand element and a
+// wave splits (TL + TD) 32-wide tiles for TL x TD x 6 matrix instructions.  At 2 x 2 tiles that
+// is 7.3 VALU per v_mfma_f32_32x32x16_bf16 (issue-bound: 8 + 4 x 7.3 > 32 cycles per product,
+// measured 3.2 ms on config 4); at 4 x 4 tiles it is 3.7, which hides under the 32-cycle product
+// (MI355X_MICROARCH.md: up to 5 single-issue fillers per gap are free at one wave per SIMD).
 //
 // Ring of 3 slots, ONE workgroup barrier per k-step, software-pipelined by one k-step:
 //     wait until this wave's pieces of k-step ks+1 have landed (counted vmcnt)
@@ -23,21 +29,65 @@
 
 namespace bnpvi {
 
-constexpr int kWideWaves = 8;
+constexpr int kWideWaves = 4;
+constexpr int kWideT = 4;               // 32-wide tiles per wave, both ways (128 x 128)
 constexpr int kWideRing = 3;
 
 template <int LBW, int DBW>
 struct WideSlot {
-  static constexpr int kAL = 64 * LBW;                  // leaves per workgroup
-  static constexpr int kBD = 64 * DBW;                  // dims per workgroup
+  static constexpr int kAL = 32 * kWideT * LBW;                  // leaves per workgroup
+  static constexpr int kBD = 32 * kWideT * DBW;                  // dims per workgroup
   static constexpr int kA = kKStep * kAL;               // floats of the phi block
   static constexpr int kB = kKStep * kBD;               // floats of the Z block
   static constexpr int kFloats = kA + kB + 64;          // + the video ids (16 used)
   static constexpr int kPA = kA / 256;                  // 1 KiB pieces of the phi block
   static constexpr int kPT = (kA + kB) / 256;           // ... of both blocks
   static constexpr int kPW = kPT / kWideWaves;          // pieces per wave
-  static_assert(LBW * DBW == kWideWaves, "8 waves per workgroup");
+  static_assert(LBW * DBW == kWideWaves, "4 waves per workgroup");
   static_assert(kPT % kWideWaves == 0, "pieces must divide evenly over the waves");
+};
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Where the pieces of the next k-step's split go between the matrix instructions of this one.
+// Tile t (t < TD: Z tiles, then the phi tiles) has 4 element pairs, a pair is split in three
+// stages of 4 + 4 + 3 VALU operations; stage idx = 12 t + 3 pair + st runs behind product
+// stage_pos(idx), tile t is read from LDS ~9 products ahead of its first stage.
+template <int TL, int TD>
+struct WideSched {
+  static constexpr int NT = TL + TD, NM = TL * TD * 6, NS = 12 * NT;
+  static constexpr int kLead = 3;                         // products before the first stage
+  static_assert(NS <= NM, "at most about one split stage per product");
+  static constexpr int stage_pos(int idx) { return kLead + (idx * (NM - 1 - kLead)) / (NS - 1); }
+  static constexpr int first_stage_at(int g) {
+    int idx = 0;
+    while (idx < NS && stage_pos(idx) < g) ++idx;
+    return idx;
+  }
+  static constexpr int stages_at(int g) {
+    int n = 0;
+    for (int idx = 0; idx < NS; ++idx) n += stage_pos(idx) == g;
+    return n;
+  }
+  static constexpr int load_pos(int t) { return stage_pos(12 * t) > 9 ? stage_pos(12 * t) - 9 : 0; }
+  static constexpr int load_at(int g) {                   // tile to read behind product g, or -1
+    for (int t = 1; t < NT; ++t)
+      if (load_pos(t) == g) return t;
+    return -1;
+  }
+  static constexpr int max_stages() {
+    int m = 0;
+    for (int g = 0; g < NM; ++g) m = stages_at(g) > m ? stages_at(g) : m;
+    return m;
+  }
 };
 
 __device__ __forceinline__ void wide_barrier() {
@@ -52,7 +102,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   using Slot = WideSlot<LBW, DBW>;
   constexpr int R = kWideRing;
   constexpr int AL = Slot::kAL, BD = Slot::kBD, PW = Slot::kPW;
-  constexpr int TL = 2, TD = 2;
+  constexpr int TL = kWideT, TD = kWideT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* ring = reinterpret_cast<float*>(smem_raw);                // [R][Slot::kFloats]
 
@@ -68,14 +118,17 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   const int wl = wave % LBW, wd = wave / LBW;                      // sub-tile of this wave
   const int i = lane & 31;
   const int h = lane >> 5;
-  const bool lead = (bz == 0) && (wd == 0);                        // S0 / masses of its leaves
+  // S0 and the masses: the DBW waves that share a row of leaf tiles each take TL / DBW of them
+  constexpr int TS = kWideT / DBW;
+  static_assert(TS * DBW == kWideT, "leaf tiles must divide over the waves of a row");
+  const bool lead = (bz == 0);
   const bool do_mass = lead && (mass != nullptr);
 
   const int64_t n0 = (int64_t)cx * chunk < N ? (int64_t)cx * chunk : N;
   const int64_t n1 = (n0 + chunk < N) ? n0 + chunk : N;
   const int64_t nsteps = (n1 - n0 + kKStep - 1) / kKStep;          // same for all waves of the workgroup
 
-  // ---- this wave's DMA pieces: piece p = wave + 8 q covers floats [256 p, 256 p + 256) of the slot
+  // ---- this wave's DMA pieces: piece p = wave + 4 q covers floats [256 p, 256 p + 256) of the slot
   // Per piece: a wave-uniform base pointer and row pitch (scalar registers) and ONE per-lane
   // 32-bit element offset that never changes (row-in-k-step * pitch + column); the k-step's
   // first row is added to the uniform part.
@@ -104,14 +157,19 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     }
   }
   const unsigned l15 = (unsigned)(lane & 15);
-  auto issue = [&](int64_t ks) __attribute__((always_inline)) {
-    float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
+  // one DMA instruction of a WHOLE k-step: piece q < PW, or (q == PW) the video ids
+  auto issue_piece = [&](int q, int64_t f0, float* slot) __attribute__((always_inline)) {
+    if (q < PW)
+      dma16(src_base[q] + f0 * src_ld[q] + src_off[q], slot + 256 * (wave + kWideWaves * q));
+    else
+      dma4(vid + f0 + l15, slot + Slot::kA + Slot::kB);            // every wave: same 64 bytes, same place
+  };
+  auto issue = [&](int64_t ks, int m) __attribute__((always_inline)) {
+    float* slot = ring + (size_t)m * Slot::kFloats;
     const int64_t f0 = n0 + ks * kKStep;
     if (__builtin_expect(f0 + kKStep <= n1, 1)) {                  // wave-uniform
 #pragma unroll
-      for (int q = 0; q < PW; ++q)
-        dma16(src_base[q] + f0 * src_ld[q] + src_off[q], slot + 256 * (wave + kWideWaves * q));
-      dma4(vid + f0 + l15, slot + Slot::kA + Slot::kB);            // every wave: same 64 bytes, same place
+      for (int q = 0; q <= PW; ++q) issue_piece(q, f0, slot);
     } else {                                                       // ragged tail: re-read the last valid row
 #pragma unroll
       for (int q = 0; q < PW; ++q) {
@@ -133,32 +191,31 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     for (int b = 0; b < TD; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float s0[TL], msum[TL];
-  int lcol[TL];
+  float s0[TS], msum[TS];
+  int lcol[TS];
 #pragma unroll
-  for (int a = 0; a < TL; ++a) {
+  for (int a = 0; a < TS; ++a) {
     s0[a] = msum[a] = 0.f;
-    lcol[a] = by * AL + wl * 64 + 32 * a + i;
+    lcol[a] = by * AL + wl * (32 * TL) + 32 * (wd * TS + a) + i;
   }
   int my_vid = -1;
   auto flush_mass = [&]() __attribute__((always_inline)) {
     if (my_vid >= 0) {
 #pragma unroll
-      for (int a = 0; a < TL; ++a)
+      for (int a = 0; a < TS; ++a)
         if (lcol[a] < L && msum[a] != 0.f) atomicAdd(&mass[(int64_t)my_vid * L + lcol[a]], (double)msum[a]);
     }
 #pragma unroll
-    for (int a = 0; a < TL; ++a) msum[a] = 0.f;
+    for (int a = 0; a < TS; ++a) msum[a] = 0.f;
   };
 
   struct Ops {
     Frag ah[TL], am[TL], al[TL], bh[TD], bm[TD], bl[TD];
   };
   // raw operands of k-step ks out of its LDS slot; MASK: zero the phi rows past the chunk's end
-  auto load_a = [&](int64_t ks, int a, auto mask_c, float (&x)[8]) __attribute__((always_inline)) {
-    const float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
+  auto load_a = [&](const float* slot, int64_t ks, int a, auto mask_c, float (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = slot[(8 * h + e) * AL + wl * 64 + 32 * a + i];
+    for (int e = 0; e < 8; ++e) x[e] = slot[(8 * h + e) * AL + wl * (32 * TL) + 32 * a + i];
     if constexpr (decltype(mask_c)::value) {
       const int64_t f0 = n0 + ks * kKStep;
 #pragma unroll
@@ -166,38 +223,39 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
         if (f0 + 8 * h + e >= n1) x[e] = 0.f;
     }
   };
-  auto load_b = [&](int64_t ks, int b, float (&x)[8]) __attribute__((always_inline)) {
-    const float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
+  auto load_b = [&](const float* slot, int b, float (&x)[8]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = slot[Slot::kA + (8 * h + e) * BD + wd * 64 + 32 * b + i];
+    for (int e = 0; e < 8; ++e) x[e] = slot[Slot::kA + (8 * h + e) * BD + wd * (32 * TD) + 32 * b + i];
   };
-  // S0 and the per-video masses of k-step ks (lead waves only)
-  // (reads its phi rows again: two of the eight waves do, and the others keep 16 registers)
-  auto lead_stats = [&](int64_t ks) __attribute__((always_inline)) {
-    const float* slot = ring + (size_t)(ks % R) * Slot::kFloats;
+  // S0 and the per-video masses of k-step ks from this wave's share of the phi tiles.  The rows
+  // are read a second time (unmasked, by load_stat, early enough for the latency to hide).
+  auto load_stat = [&](const float* slot, float (&xs)[TS][8]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int a = 0; a < TS; ++a) load_a(slot, 0, wd * TS + a, std::false_type{}, xs[a]);
+  };
+  auto lead_stats = [&](const float* slot, int64_t ks, float (&xa)[TS][8]) __attribute__((always_inline)) {
     const int64_t f0 = n0 + ks * kKStep;
     const bool ragged = f0 + kKStep > n1;
-    float xa[TL][8];
+    if (ragged) {
 #pragma unroll
-    for (int a = 0; a < TL; ++a) {
-      if (ragged)
-        load_a(ks, a, std::true_type{}, xa[a]);
-      else
-        load_a(ks, a, std::false_type{}, xa[a]);
+      for (int a = 0; a < TS; ++a)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (f0 + 8 * h + e >= n1) xa[a][e] = 0.f;
     }
     const int* vslot = reinterpret_cast<const int*>(slot + Slot::kA + Slot::kB);
     bool same_video = !do_mass;
     if (do_mass && !ragged) same_video = __ballot(vslot[lane & 15] != my_vid) == 0ull;
-    float t[TL];
+    float t[TS];
 #pragma unroll
-    for (int a = 0; a < TL; ++a) {
+    for (int a = 0; a < TS; ++a) {
       t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
       s0[a] += t[a];
       asm volatile("" : "+v"(s0[a]));        // see mstep_dma.hip: keep the S0 update ahead of the divergent path
     }
     if (__builtin_expect(same_video, 1)) {
 #pragma unroll
-      for (int a = 0; a < TL; ++a) msum[a] += t[a];
+      for (int a = 0; a < TS; ++a) msum[a] += t[a];
     } else {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -207,7 +265,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
           my_vid = ve;
         }
 #pragma unroll
-        for (int a = 0; a < TL; ++a) msum[a] += xa[a][e];
+        for (int a = 0; a < TS; ++a) msum[a] += xa[a][e];
       }
     }
   };
@@ -220,55 +278,93 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   // One k-step of the software pipeline: the matrix products of k-step ks (operands `cur`,
   // already split) run while the VALU splits k-step ks+1 out of LDS into `nxt`, so the two
   // pipes of a SIMD overlap inside one wave (with one barrier per k-step the waves of a
-  // workgroup move in lockstep and cannot cover for each other).
-  auto step = [&](int64_t ks, auto mask_c, const Ops& cur, Ops& nxt) __attribute__((always_inline)) {
-    if (ks + 2 < nsteps)
+  // workgroup move in lockstep and cannot cover for each other).  m1 = ring slot of ks+1; k-step
+  // ks+3 goes into the slot of ks.  FAST (main loop): ks+2 and a whole ks+3 exist, and the DMA
+  // instructions of ks+3 are placed between the products too.
+  auto next_slot = [](int m) { return m == R - 1 ? 0 : m + 1; };
+  auto step = [&](int64_t ks, int m1, auto mask_c, auto fast_c, const Ops& cur, Ops& nxt)
+                  __attribute__((always_inline)) {
+    constexpr bool kFast = decltype(fast_c)::value;
+    const int m3 = next_slot(next_slot(m1));
+    const float* slot1 = ring + (size_t)m1 * Slot::kFloats;
+    float* slot3 = ring + (size_t)m3 * Slot::kFloats;
+    const int64_t f3 = n0 + (ks + 3) * kKStep;
+    if (kFast || ks + 2 < nsteps)
       wait_vmcnt<P>();          // only the pieces of ks+2 may still be in flight
     else
       wait_vmcnt<0>();
     wide_barrier();             // everybody's pieces of ks+1 are in LDS, everybody is done reading ks
-    if (ks + 3 < nsteps) issue(ks + 3);
-    static_assert(TL == 2 && TD == 2, "interleave written for 2 x 2 tiles");
-    // Hand-placed schedule (fences keep the compiler from bunching the 24 matrix instructions and
-    // doing the ~180 VALU operations of the split afterwards): tile t of k-step ks+1 (0,1 = Z
-    // tiles, 2,3 = phi tiles) is read from LDS a few products ahead of its split, and the 16
-    // element pairs of the split are spread over products 3..23.
-    float x[4][8];
+#ifndef BNPVI_MABLATE_NOLOAD
+    if constexpr (!kFast) {
+      if (ks + 3 < nsteps) issue(ks + 3, m3);
+    }
+#endif
+    // Hand-placed schedule (WideSched; fences keep the compiler from bunching the matrix
+    // instructions and doing the VALU work of the split afterwards).
+    using Sched = WideSched<TL, TD>;
+    constexpr int NT = Sched::NT;
+    float x[NT][8];
     auto ld = [&](int t) __attribute__((always_inline)) {
-      if (t < 2)
-        load_b(ks + 1, t, x[t]);
+      if (t < TD)
+        load_b(slot1, t, x[t]);
       else
-        load_a(ks + 1, t - 2, mask_c, x[t]);
+        load_a(slot1, ks + 1, t - TD, mask_c, x[t]);
     };
-    auto sp = [&](int t, int q) __attribute__((always_inline)) {
-      Frag& H = t == 0 ? nxt.bh[0] : t == 1 ? nxt.bh[1] : t == 2 ? nxt.ah[0] : nxt.ah[1];
-      Frag& M = t == 0 ? nxt.bm[0] : t == 1 ? nxt.bm[1] : t == 2 ? nxt.am[0] : nxt.am[1];
-      Frag& Lo = t == 0 ? nxt.bl[0] : t == 1 ? nxt.bl[1] : t == 2 ? nxt.al[0] : nxt.al[1];
-      split_pair(x[t][2 * q], x[t][2 * q + 1], H.u[q], M.u[q], Lo.u[q]);
-      // the results are used one k-step later: without this the optimiser sinks the arithmetic there
-      asm volatile("" : "+v"(H.u[q]), "+v"(M.u[q]), "+v"(Lo.u[q]));
+    float r0 = 0.f, r1 = 0.f, q0 = 0.f, q1 = 0.f;       // residuals of the pair being split
+    auto stage = [&](int t, int q, int st) __attribute__((always_inline)) {
+      const float x0 = x[t][2 * q], x1 = x[t][2 * q + 1];
+#ifdef BNPVI_MABLATE_NOSPLIT
+      if (st < 2) return;
+      r0 = q0 = x0;
+      r1 = q1 = x1;
+#endif
+      if (st == 0) {
+        r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
+        r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        asm volatile("" : "+v"(r0), "+v"(r1));
+      } else if (st == 1) {
+        q0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+        q1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        asm volatile("" : "+v"(q0), "+v"(q1));
+      } else {
+        Frag& H = t < TD ? nxt.bh[t] : nxt.ah[t - TD];
+        Frag& M = t < TD ? nxt.bm[t] : nxt.am[t - TD];
+        Frag& Lo = t < TD ? nxt.bl[t] : nxt.al[t - TD];
+        H.u[q] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        M.u[q] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        Lo.u[q] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+        // used one k-step later: without this the optimiser sinks the arithmetic there
+        asm volatile("" : "+v"(H.u[q]), "+v"(M.u[q]), "+v"(Lo.u[q]));
+      }
     };
+    float xs[TS][8];
     ld(0);
-#pragma unroll
-    for (int g = 0; g < 24; ++g) {
-      const int a = g / 12, b = (g / 6) % 2;
+    static_for<Sched::NM>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int a = (g / 6) / TD, b = (g / 6) % TD;
       mac1(g % 6, cur.ah[a], cur.am[a], cur.al[a], cur.bh[b], cur.bm[b], cur.bl[b], acc[a][b]);
       __builtin_amdgcn_sched_barrier(0);
-      if (g == 1) ld(1);
-      if (g == 6) ld(2);
-      if (g == 11) ld(3);
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (3 + (j * 20) / 15 == g) sp(j / 4, j % 4);
+      if constexpr (Sched::load_at(g) >= 0) ld(Sched::load_at(g));
+      if constexpr (g == Sched::NM - 8) load_stat(slot1, xs);
+#ifndef BNPVI_MABLATE_NOLOAD
+      if constexpr (kFast && g >= 2 && g % 2 == 0 && (g - 2) / 2 <= PW) issue_piece((g - 2) / 2, f3, slot3);
+#endif
+      static_for<Sched::max_stages()>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < Sched::stages_at(g)) {
+          constexpr int idx = Sched::first_stage_at(g) + k;
+          stage(idx / 12, (idx / 3) % 4, idx % 3);
+        }
+      });
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (lead) lead_stats(ks + 1);
+    });
+    if (lead) lead_stats(slot1, ks + 1, xs);
   };
 
   if (nsteps > 0) {
-    issue(0);
-    if (nsteps > 1) issue(1);
-    if (nsteps > 2) issue(2);
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    if (nsteps > 2) issue(2, 2);
     if (nsteps > 2)
       wait_vmcnt<2 * P>();
     else if (nsteps > 1)
@@ -281,32 +377,34 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       float x[8];
 #pragma unroll
       for (int b = 0; b < TD; ++b) {
-        load_b(0, b, x);
+        load_b(ring, b, x);
         split3(x, A.bh[b], A.bm[b], A.bl[b]);
       }
 #pragma unroll
       for (int a = 0; a < TL; ++a) {
-        load_a(0, a, std::true_type{}, x);
+        load_a(ring, 0, a, std::true_type{}, x);
         split3(x, A.ah[a], A.am[a], A.al[a]);
       }
-      if (lead) lead_stats(0);
+      if (lead) {
+        float xs[TS][8];
+        load_stat(ring, xs);
+        lead_stats(ring, 0, xs);
+      }
     }
     int64_t ks = 0;
-    for (; ks + 3 < nsteps; ks += 2) {       // k-steps ks+1, ks+2 are whole
-      step(ks, std::false_type{}, A, B);
-      step(ks + 1, std::false_type{}, B, A);
+    int m1 = 1;                              // ring slot of k-step ks+1
+    for (; ks + 5 < nsteps; ks += 2) {       // k-steps up to ks+4 are whole
+      step(ks, m1, std::false_type{}, std::true_type{}, A, B);
+      m1 = next_slot(m1);
+      step(ks + 1, m1, std::false_type{}, std::true_type{}, B, A);
+      m1 = next_slot(m1);
     }
-    const int64_t rem = nsteps - ks;         // 1, 2 or 3 left; only the last one can be ragged
-    if (rem == 3) {
-      step(ks, std::false_type{}, A, B);
-      step(ks + 1, std::true_type{}, B, A);
-      mac_all(A);
-    } else if (rem == 2) {
-      step(ks, std::true_type{}, A, B);
-      mac_all(B);
-    } else {
-      mac_all(A);
+    for (; ks + 1 < nsteps; ++ks) {          // the last few k-steps (the last one may be ragged)
+      step(ks, m1, std::true_type{}, std::false_type{}, A, B);
+      m1 = next_slot(m1);
+      A = B;
     }
+    mac_all(A);
   }
   if (do_mass) flush_mass();
 
@@ -316,16 +414,16 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   for (int a = 0; a < TL; ++a)
 #pragma unroll
     for (int b = 0; b < TD; ++b) {
-      const int dim = bz * BD + wd * 64 + 32 * b + i;
+      const int dim = bz * BD + wd * (32 * TD) + 32 * b + i;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int leaf = by * AL + wl * 64 + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int leaf = by * AL + wl * (32 * TL) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
         if (leaf < L && dim < D) out[(int64_t)leaf * W + 1 + dim] = (double)acc[a][b][r];
       }
     }
   if (lead) {
 #pragma unroll
-    for (int a = 0; a < TL; ++a) {
+    for (int a = 0; a < TS; ++a) {
       const float t = s0[a] + __shfl_xor(s0[a], 32);
       if (h == 0 && lcol[a] < L) out[(int64_t)lcol[a] * W] = (double)t;
     }
@@ -338,14 +436,16 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   using Slot = WideSlot<LBW, DBW>;
   const int gy = (int)ceil_div(ldphi, Slot::kAL), gz = ldz / Slot::kBD;
   const size_t lds = (size_t)kWideRing * Slot::kFloats * sizeof(float);
-  // enough workgroups for ~4 per CU, chunks of at most kMaxChunk frames (fp32 partial sums)
-  // one workgroup per CU at a time (LDS ring + registers): a whole number of rounds, about 4
-  int64_t gx = (int64_t)4 * ctx->num_cu / ((int64_t)gy * gz);
-  if (gx < 1) gx = 1;
+  // One workgroup per CU at a time (LDS ring + 512 registers per wave).  About two rounds of
+  // workgroups, the number of chunks a multiple of 8 (chunk cx runs on XCD cx % 8, so anything else
+  // leaves one XCD a round behind), chunks of at most kMaxChunk frames (fp32 partial sums); long
+  // chunks keep the fp64 slab traffic (gx L W 8 bytes, written and reduced) small.
+  int64_t gx = (int64_t)2 * ctx->num_cu / ((int64_t)gy * gz);
+  gx = gx >= 8 ? gx / 8 * 8 : (gx < 1 ? 1 : gx);
+  if (ceil_div(N, gx) > kMaxChunk) gx = ceil_div(ceil_div(N, (int64_t)kMaxChunk), 8) * 8;
   int64_t chunk = ceil_div(N, gx);
   chunk = (chunk + kKStep - 1) / kKStep * kKStep;
   if (chunk < 8 * kKStep) chunk = 8 * kKStep;
-  if (chunk > kMaxChunk) chunk = kMaxChunk;
   gx = ceil_div(N, chunk);
   const int64_t blocks = ceil_div(gx, 8) * 8 * gy * gz;
   BNPVI_REQUIRE(blocks < (int64_t(1) << 31), "leaf_stats: grid of %lld workgroups", (long long)blocks);
@@ -368,10 +468,9 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
   const int W = 1 + D;
   // workgroup-wide tiles: worth it from ~1000 leaves on, need D padded to >= 128
   if (N < kKStep || (ldphi % 4) || (ldz % 128) || vid == nullptr || ldphi < 4 * 256) return BNPVI_EUNSUPPORTED;
-  // full-width dim tiles when D is padded to 256 (phi is then read exactly once; measured 4 % faster
-  // than 256 x 128 at 512k frames), else 256 leaves x 128 dims
-  if (ldz % 256 == 0) return run_wide<2, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  return run_wide<4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  // 256 leaves x 256 dims when D is padded to 256 (phi is then read exactly once), else 512 x 128
+  if (ldz % 256 == 0) return run_wide<2, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  return run_wide<4, 1>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
 }
 
 }  // namespace bnpvi
