@@ -229,11 +229,12 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   };
   // S0 and the per-video masses of k-step ks from this wave's share of the phi tiles.  The rows
   // are read a second time (unmasked, by load_stat, early enough for the latency to hide).
-  auto load_stat = [&](const float* slot, float (&xs)[TS][8]) __attribute__((always_inline)) {
+  auto load_stat = [&](const float* slot, float (&xs)[TS][8], int& v15) __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < TS; ++a) load_a(slot, 0, wd * TS + a, std::false_type{}, xs[a]);
+    v15 = reinterpret_cast<const int*>(slot + Slot::kA + Slot::kB)[lane & 15];
   };
-  auto lead_stats = [&](const float* slot, int64_t ks, float (&xa)[TS][8]) __attribute__((always_inline)) {
+  auto lead_stats = [&](const float* slot, int64_t ks, float (&xa)[TS][8], int v15) __attribute__((always_inline)) {
     const int64_t f0 = n0 + ks * kKStep;
     const bool ragged = f0 + kKStep > n1;
     if (ragged) {
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     }
     const int* vslot = reinterpret_cast<const int*>(slot + Slot::kA + Slot::kB);
     bool same_video = !do_mass;
-    if (do_mass && !ragged) same_video = __ballot(vslot[lane & 15] != my_vid) == 0ull;
+    if (do_mass && !ragged) same_video = __ballot(v15 != my_vid) == 0ull;
     float t[TS];
 #pragma unroll
     for (int a = 0; a < TS; ++a) {
@@ -338,6 +339,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       }
     };
     float xs[TS][8];
+    int v15 = 0;
     ld(0);
     static_for<Sched::NM>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       mac1(g % 6, cur.ah[a], cur.am[a], cur.al[a], cur.bh[b], cur.bm[b], cur.bl[b], acc[a][b]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (Sched::load_at(g) >= 0) ld(Sched::load_at(g));
-      if constexpr (g == Sched::NM - 8) load_stat(slot1, xs);
+      if constexpr (g == Sched::NM - 8) load_stat(slot1, xs, v15);
 #ifndef BNPVI_MABLATE_NOLOAD
       if constexpr (kFast && g >= 2 && g % 2 == 0 && (g - 2) / 2 <= PW) issue_piece((g - 2) / 2, f3, slot3);
 #endif
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       });
       __builtin_amdgcn_sched_barrier(0);
     });
-    if (lead) lead_stats(slot1, ks + 1, xs);
+    if (lead) lead_stats(slot1, ks + 1, xs, v15);
   };
 
   if (nsteps > 0) {
@@ -387,8 +389,9 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       }
       if (lead) {
         float xs[TS][8];
-        load_stat(ring, xs);
-        lead_stats(ring, 0, xs);
+        int v15;
+        load_stat(ring, xs, v15);
+        lead_stats(ring, 0, xs, v15);
       }
     }
     int64_t ks = 0;
