@@ -543,7 +543,7 @@ def test_path_prior_branch_of_get_true_path_mean():
 # --------------------------------------------------------------------------------------------
 # BASELINE.json's full sizes: no oracle run is affordable there, so the checks are size-independent
 # properties of one VI iteration (and of its parts) on the synthetic benchmark workload.
-@pytest.mark.parametrize("cfg,N", [("config2", 999_936), ("config3", 262_144)])
+@pytest.mark.parametrize("cfg,N", [("config2", 999_936), ("config3", 262_144), ("config4", 32_768)])
 def test_full_size_properties(cfg, N):
     import torch
     from bench import CONFIGS, regular_tree, make_latents
@@ -612,4 +612,45 @@ def test_full_size_properties(cfg, N):
     dev.leaf_stats(want_q=False, want_mass=False)
     torch.cuda.synchronize()
     assert torch.equal(dev.stats, st)
+    dev.close()
+
+
+@pytest.mark.parametrize("N,D,L,fpv", [
+    (40_000, 128, 1024, 100),      # 512-leaf x 128-dim workgroup tiles, video boundaries inside k-steps
+    (24_577, 200, 1500, 77),       # 256 x 256 tiles, D and L padded, ragged last k-step
+])
+def test_wide_mstep_against_fp64(N, D, L, fpv):
+    """mstep_wide.hip on long chunks (hundreds of k-steps through the 3-slot ring) with video
+    boundaries that fall inside k-steps: S0, S1 and the per-video masses against torch fp64."""
+    import torch
+    from bnp_vae_amd.engine import DeviceVI
+    parent = np.concatenate([[-1], np.zeros(L, np.int32)]).astype(np.int32)      # root + L leaves
+    is_leaf = np.concatenate([[0], np.ones(L, np.uint8)]).astype(np.uint8)
+    dev = DeviceVI(device=0)
+    g = torch.Generator(device=dev.device)
+    g.manual_seed(5)
+    Z = torch.randn((N, D), generator=g, device=dev.device) * 3.0
+    vid = (torch.arange(N, device=dev.device) // fpv).to(torch.int32)
+    V = int(vid[-1]) + 1
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.zeros((L + 1, D)), np.ones(L + 1))
+    logits = torch.randn((N, L), generator=g, device=dev.device) * 4.0
+    dev.alloc_phi()
+    dev.phi[:, :L] = torch.softmax(logits, dim=1)
+    del logits
+    assert dev.tree.Lp >= 1024 and dev.Dp % 128 == 0                              # the wide kernel's regime
+    dev.leaf_stats(want_q=False, want_mass=True)
+    torch.cuda.synchronize()
+    phi64 = dev.phi[:, :L].to(torch.float64)
+    s0 = phi64.sum(dim=0)
+    s1 = phi64.T @ Z.to(torch.float64)
+    mass = torch.zeros((V, L), dtype=torch.float64, device=dev.device).index_add_(0, vid.long(), phi64)
+    st = dev.stats
+    np.testing.assert_allclose(st[:, 0].cpu().numpy(), s0.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    assert float((st[:, 1:1 + D] - s1).abs().max()) <= 2e-6 * float(s1.abs().max())
+    np.testing.assert_allclose(dev.mass[:, :L].cpu().numpy(), mass.cpu().numpy(), rtol=2e-6, atol=1e-7)
+    first = st.clone()
+    dev.leaf_stats(want_q=False, want_mass=False)
+    torch.cuda.synchronize()
+    assert torch.equal(dev.stats, first)                                          # fixed-order reductions
     dev.close()
