@@ -30,13 +30,12 @@
 namespace bnpvi {
 
 constexpr int kWideWaves = 4;
-constexpr int kWideT = 4;               // 32-wide tiles per wave, both ways (128 x 128)
 constexpr int kWideRing = 3;
 
-template <int LBW, int DBW>
+template <int LBW, int DBW, int TL, int TD>   // waves and 32-wide tiles per wave: leaves, dims
 struct WideSlot {
-  static constexpr int kAL = 32 * kWideT * LBW;                  // leaves per workgroup
-  static constexpr int kBD = 32 * kWideT * DBW;                  // dims per workgroup
+  static constexpr int kAL = 32 * TL * LBW;                  // leaves per workgroup
+  static constexpr int kBD = 32 * TD * DBW;                  // dims per workgroup
   static constexpr int kA = kKStep * kAL;               // floats of the phi block
   static constexpr int kB = kKStep * kBD;               // floats of the Z block
   static constexpr int kFloats = kA + kB + 64;          // + the video ids (16 used)
@@ -65,7 +64,6 @@ template <int TL, int TD>
 struct WideSched {
   static constexpr int NT = TL + TD, NM = TL * TD * 6, NS = 12 * NT;
   static constexpr int kLead = 3;                         // products before the first stage
-  static_assert(NS <= NM, "at most about one split stage per product");
   static constexpr int stage_pos(int idx) { return kLead + (idx * (NM - 1 - kLead)) / (NS - 1); }
   static constexpr int first_stage_at(int g) {
     int idx = 0;
@@ -94,15 +92,14 @@ __device__ __forceinline__ void wide_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int LBW, int DBW>
+template <int LBW, int DBW, int TL, int TD>
 __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     const float* __restrict__ Z, int ldz, const float* __restrict__ phi, int ldphi,
     const int32_t* __restrict__ vid, int64_t N, int D, int L, int64_t chunk, double* __restrict__ slab,
     int W, double* __restrict__ mass, int gx, int gy, int gz) {
-  using Slot = WideSlot<LBW, DBW>;
+  using Slot = WideSlot<LBW, DBW, TL, TD>;
   constexpr int R = kWideRing;
   constexpr int AL = Slot::kAL, BD = Slot::kBD, PW = Slot::kPW;
-  constexpr int TL = kWideT, TD = kWideT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* ring = reinterpret_cast<float*>(smem_raw);                // [R][Slot::kFloats]
 
@@ -119,8 +116,8 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   const int i = lane & 31;
   const int h = lane >> 5;
   // S0 and the masses: the DBW waves that share a row of leaf tiles each take TL / DBW of them
-  constexpr int TS = kWideT / DBW;
-  static_assert(TS * DBW == kWideT, "leaf tiles must divide over the waves of a row");
+  constexpr int TS = TL / DBW;
+  static_assert(TS * DBW == TL, "leaf tiles must divide over the waves of a row");
   const bool lead = (bz == 0);
   const bool do_mass = lead && (mass != nullptr);
 
@@ -433,17 +430,19 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   }
 }
 
-template <int LBW, int DBW>
+template <int LBW, int DBW, int TL, int TD>
 static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi, const int32_t* vid,
                     int64_t N, int D, int L, int W, double* stats, double* mass, hipStream_t s) {
-  using Slot = WideSlot<LBW, DBW>;
+  using Slot = WideSlot<LBW, DBW, TL, TD>;
   const int gy = (int)ceil_div(ldphi, Slot::kAL), gz = ldz / Slot::kBD;
   const size_t lds = (size_t)kWideRing * Slot::kFloats * sizeof(float);
   // One workgroup per CU at a time (LDS ring + 512 registers per wave).  About two rounds of
   // workgroups, the number of chunks a multiple of 8 (chunk cx runs on XCD cx % 8, so anything else
   // leaves one XCD a round behind), chunks of at most kMaxChunk frames (fp32 partial sums); long
   // chunks keep the fp64 slab traffic (gx L W 8 bytes, written and reduced) small.
-  int64_t gx = (int64_t)2 * ctx->num_cu / ((int64_t)gy * gz);
+  int rounds = 2;
+  if (const char* e = getenv("BNPVI_WIDE_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  int64_t gx = (int64_t)rounds * ctx->num_cu / ((int64_t)gy * gz);
   gx = gx >= 8 ? gx / 8 * 8 : (gx < 1 ? 1 : gx);
   if (ceil_div(N, gx) > kMaxChunk) gx = ceil_div(ceil_div(N, (int64_t)kMaxChunk), 8) * 8;
   int64_t chunk = ceil_div(N, gx);
@@ -454,7 +453,7 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   BNPVI_REQUIRE(blocks < (int64_t(1) << 31), "leaf_stats: grid of %lld workgroups", (long long)blocks);
   int rc = ctx->slabs.ensure((size_t)gx * L * W * sizeof(double));
   if (rc) return rc;
-  auto kern = leaf_stats_wide_kernel<LBW, DBW>;
+  auto kern = leaf_stats_wide_kernel<LBW, DBW, TL, TD>;
   BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWideWaves * 64), lds, s, Z, ldz, phi, ldphi, vid, N, D, L,
@@ -469,11 +468,15 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
                            hipStream_t s) {
   (void)V;
   const int W = 1 + D;
-  // workgroup-wide tiles: worth it from ~1000 leaves on, need D padded to >= 128
-  if (N < kKStep || (ldphi % 4) || (ldz % 128) || vid == nullptr || ldphi < 4 * 256) return BNPVI_EUNSUPPORTED;
-  // 256 leaves x 256 dims when D is padded to 256 (phi is then read exactly once), else 512 x 128
-  if (ldz % 256 == 0) return run_wide<2, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  return run_wide<4, 1>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  if (N < kKStep || (ldphi % 4) || vid == nullptr) return BNPVI_EUNSUPPORTED;
+  // 256 leaves x 256 dims when D is padded to 256 (phi is then read exactly once), 512 x 128 at
+  // D <= 128, both from ~1000 leaves on; 512 leaves x 64 dims (128 x 64 per wave) from 512 leaves on
+  if (ldz % 256 == 0 && ldphi >= 1024)
+    return run_wide<2, 2, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  if (ldz % 128 == 0 && ldphi >= 1024)
+    return run_wide<4, 1, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  if (ldz == 64 && ldphi >= 512) return run_wide<4, 1, 4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  return BNPVI_EUNSUPPORTED;
 }
 
 }  // namespace bnpvi
