@@ -469,11 +469,13 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
   (void)V;
   const int W = 1 + D;
   if (N < kKStep || (ldphi % 4) || vid == nullptr) return BNPVI_EUNSUPPORTED;
-  // 256 leaves x 256 dims when D is padded to 256 (phi is then read exactly once), 512 x 128 at
-  // D <= 128, both from ~1000 leaves on; 512 leaves x 64 dims (128 x 64 per wave) from 512 leaves on
-  if (ldz % 256 == 0 && ldphi >= 1024)
+  // Workgroup tiles: 256 leaves x 256 dims when D is padded to 256 (phi is then read exactly once),
+  // 512 x 128 at D <= 128, 512 x 64 at D <= 64.  Thresholds measured against the per-wave ring of
+  // mstep_dma.hip (1M frames, kernel us, ring -> wide): D=256 L=256 993 -> 737, L=343 1637 -> 1196;
+  // D=128 L=512 1040 -> 787, L=625 1606 -> 1267; D=64 L=512 (2M frames) 1113 -> 993.
+  if (ldz % 256 == 0 && ldphi >= 256)
     return run_wide<2, 2, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  if (ldz % 128 == 0 && ldphi >= 1024)
+  if (ldz % 128 == 0 && ldphi >= 512)
     return run_wide<4, 1, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz == 64 && ldphi >= 512) return run_wide<4, 1, 4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   return BNPVI_EUNSUPPORTED;

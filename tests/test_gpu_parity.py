@@ -183,6 +183,8 @@ def _regular_case(N, D, bf, levels, fpv, seed):
     (1500, 200, 7, 3, [300, 77]),     # L=343, D=200 -> 256: streamed regime, 128 KiB operand chunks staged in LDS
     (1501, 128, 4, 5, [256, 100]),    # L=1024, D=128: workgroup-wide M-step tiles (mstep_wide.hip), ragged N
     (700, 130, 6, 4, [512]),          # L=1296 (5.06 leaf blocks of 256), D=130 -> 256: partial last leaf block
+    (1800, 128, 8, 3, [256, 61]),     # L=512, D=128: one 512-leaf x 128-dim workgroup tile (mstep_wide.hip)
+    (900, 256, 23, 2, [128]),         # L=529 (2.07 blocks of 256), D=256
 ])
 def test_iteration_against_oracle(N, D, bf, levels, fpv):
     ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=7)
