@@ -627,15 +627,26 @@ __global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logi
   }
   LeafOperands lo_{a_src, aa_src, a32 + (int64_t)kLT * T0 * DP, scal[0], scal[2]};
 
-  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles;
-       tile += (int64_t)gridDim.x * kWaves) {
+  // the next tile's Z rows are requested as soon as this tile's are converted (in flight during the
+  // MFMA block, the epilogue and the stores)
+  const int64_t tstride = (int64_t)gridDim.x * kWaves;
+  float4 zA[S], zB[S];
+  {
+    const int64_t first = (int64_t)blockIdx.x * kWaves + wave;
+    if (first < ntiles) load_ztile<DP>(Z, ldz, first * kFT, N, lane, zA, zB);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * kWaves + wave; tile < ntiles; tile += tstride) {
     const int64_t n = tile * kFT + j;
     const bool ok = n < N;
     const int64_t nn = ok ? n : N - 1;
-    float4 zA[S], zB[S];
-    load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
     f32x4 d2[NT];
+#ifdef BNPVI_LOGITS_NO_PREFETCH
+    if (tile != (int64_t)blockIdx.x * kWaves + wave) load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA, zB);
     tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, -1, lo_, lane, tiles_valid, L - kLT * T0, d2);
+#else
+    tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, tile + tstride < ntiles ? (tile + tstride) * kFT : -1, lo_,
+                           lane, tiles_valid, L - kLT * T0, d2);
+#endif
     const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp + kLT * T0;
     float m = -INFINITY;
     int best = 0x7fffffff;
