@@ -81,6 +81,17 @@ struct WideSched {
       if (load_pos(t) == g) return t;
     return -1;
   }
+  // every stage is placed exactly once, every tile is read before its first stage, and no two
+  // tiles are read behind the same product (load_at returns one tile per product)
+  static constexpr bool consistent() {
+    int placed = 0;
+    for (int g = 0; g < NM; ++g) placed += stages_at(g);
+    if (placed != NS) return false;
+    for (int t = 1; t < NT; ++t) {
+      if (load_pos(t) >= stage_pos(12 * t) || load_at(load_pos(t)) != t) return false;
+    }
+    return true;
+  }
   static constexpr int max_stages() {
     int m = 0;
     for (int g = 0; g < NM; ++g) m = stages_at(g) > m ? stages_at(g) : m;
@@ -300,6 +311,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     // Hand-placed schedule (WideSched; fences keep the compiler from bunching the matrix
     // instructions and doing the VALU work of the split afterwards).
     using Sched = WideSched<TL, TD>;
+    static_assert(Sched::consistent(), "split schedule");
     constexpr int NT = Sched::NT;
     float x[NT][8];
     auto ld = [&](int t) __attribute__((always_inline)) {
