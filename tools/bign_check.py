@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Large-N sanity of the data passes (phi has more than 2^32 elements at config 3's 16M frames):
+"""Large-N sanity of the data passes (phi has more than 2^32 elements at config 3's 16M frames;
+`bign_check.py config4 1048576` does the same for the streamed E-step and the wide M-step):
 one hard E-step + two iterations, then row sums at both ends of phi, total mass and S1 of the
 last rows against torch fp64.  Development check, run by hand on the GPU box."""
 import os
@@ -17,9 +18,10 @@ def main():
     from bench import CONFIGS, regular_tree, make_latents
     from bnp_vae_amd import _lib
     from bnp_vae_amd.engine import DeviceVI
-    N, D, bf, levels = CONFIGS["config3"]
-    if len(sys.argv) > 1:
-        N = int(sys.argv[1])
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "config3"
+    N, D, bf, levels = CONFIGS[cfg]
+    if len(sys.argv) > 2:
+        N = int(sys.argv[2])
     parent, is_leaf = regular_tree(bf, levels)
     K, L = len(parent), int(is_leaf.sum())
     dev = DeviceVI(device=0)
@@ -51,7 +53,7 @@ def main():
     assert abs(float(dev.mass.sum()) - N) <= 1e-6 * N
     # S1 through linearity: statistics of the last 1M frames alone against torch fp64
     import ctypes as C
-    lo = N - min(N, 1_000_192)
+    lo = N - min(N, 1_000_192, ((1 << 30) // L) // 256 * 256)        # fp64 copy of the slice stays under 8 GB
     out = torch.empty_like(st)
     _lib.check(_lib.lib.bnpvi_leaf_stats(
         dev.ctx, C.c_void_p(dev.Z.data_ptr() + 4 * lo * dev.Dp), dev.Dp,
