@@ -663,3 +663,15 @@ def test_wide_mstep_against_fp64(N, D, L, fpv):
     torch.cuda.synchronize()
     np.testing.assert_allclose(dev.mass.cpu().numpy(), first_mass.cpu().numpy(), rtol=1e-12, atol=1e-12)
     dev.close()
+
+
+def test_phi_beyond_32bit_element_indices():
+    """Config-3 shape with 8.5M frames: phi has 4.35e9 elements, so every row offset past the middle
+    needs 64-bit arithmetic (row kernel, wide M-step, slab reductions).  Checks in tools/bign_check.py:
+    row sums at both ends and the middle, total mass, S1 of the last 1M frames against torch fp64."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "bign_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bign_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main("config3", 8_500_224)

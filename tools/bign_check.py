@@ -13,15 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(cfg="config3", N=None):
     import torch
     from bench import CONFIGS, regular_tree, make_latents
     from bnp_vae_amd import _lib
     from bnp_vae_amd.engine import DeviceVI
-    cfg = sys.argv[1] if len(sys.argv) > 1 else "config3"
-    N, D, bf, levels = CONFIGS[cfg]
-    if len(sys.argv) > 2:
-        N = int(sys.argv[2])
+    n_cfg, D, bf, levels = CONFIGS[cfg]
+    N = int(N) if N else n_cfg
     parent, is_leaf = regular_tree(bf, levels)
     K, L = len(parent), int(is_leaf.sum())
     dev = DeviceVI(device=0)
@@ -70,4 +68,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(*sys.argv[1:3])
