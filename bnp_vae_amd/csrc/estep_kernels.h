@@ -116,7 +116,7 @@ struct NoLoads {
 
 // more_loads(): further global loads of the caller, issued together with the next tile's Z rows
 // (after this tile's rows have been consumed, before the MFMA block that hides their latency).
-template <int DP, int NT, class MoreLoads = NoLoads>
+template <int DP, int NT, class MoreLoads = NoLoads, bool ALWAYS_NEXT = false>
 __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int ldz, int64_t row0,
                                                int64_t N, float4 (&zA)[DP / 32],
                                                float4 (&zB)[DP / 32], int64_t next_row0,
@@ -142,10 +142,20 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   f16x8 bh[S], bl[S];
 #pragma unroll
   for (int s = 0; s < S; ++s) split8(zA[s], zB[s], sz, bh[s], bl[s]);
-#ifndef BNPVI_LATE_PREFETCH
+  // Order matters for the vmcnt bookkeeping (in-order completion): the caller's loads for THIS tile
+  // (prior entries, addressed through a video index that arrived a tile ago) are issued first, the
+  // next tile's Z rows after them.  The other way round the wait for the video index is a
+  // vmcnt(0) right behind the Z prefetch -- a full HBM round trip exposed on every tile.
+#ifdef BNPVI_PRIOR_AFTER_Z
   if (next_row0 >= 0) load_ztile<DP>(Z, ldz, next_row0, N, lane, zA, zB);
-#endif
   more_loads();
+#else
+  more_loads();
+  __builtin_amdgcn_sched_barrier(0);
+  // ALWAYS_NEXT: the prefetch is unconditional (the caller passes a valid row), so the loop body
+  // is straight-line code and the compiler's vmcnt counts are exact, not a merge over branches
+  if (ALWAYS_NEXT || next_row0 >= 0) load_ztile<DP>(Z, ldz, next_row0, N, lane, zA, zB);
+#endif
 
   // every tile's MFMAs run unconditionally (operands of tiles past the padded leaves are zero)
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -275,6 +285,17 @@ struct FusedParams {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// phi is written once and next read by another kernel, after Z has gone by again: stored with the
+// non-temporal policy so that it does not push the Z rows out of the memory-side cache
+// (BNPVI_PHI_STORE_PLAIN rebuilds the default-policy variant for A/B runs).
+__device__ __forceinline__ void store_phi4(float* dst, const f32x4& v) {
+#ifdef BNPVI_PHI_STORE_PLAIN
+  *reinterpret_cast<f32x4*>(dst) = v;
+#else
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+#endif
+}
+
 // Generic epilogue of a tile (hard mode, or log phi / arg-max asked for): natural-log logits,
 // arg-max tracking, phi = exp(log phi).
 template <int NT, bool HARD, bool STATS>
@@ -365,7 +386,7 @@ __device__ __forceinline__ void tile_epilogue_generic(const FusedParams& p, int6
 // Fast epilogue (soft responsibilities only, the production path of compute_phi): log2-domain
 // logits straight from the log2-unit prior table, one exponential per entry, phi = e / sum,
 // pairs of entries on the packed fp32 pipe, one store block per frame.
-template <int NT, int TV, bool STATS>
+template <int NT, int TV, bool STATS, bool FULL = false>
 __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t n, bool ok, int lane,
                                                    int tiles_valid, const float* prow,
                                                    const float4 (&pre)[NT] /* prior entries, TV > 0 only */,
@@ -405,7 +426,7 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
   }
   const float ssum = cols4_sum(ss[0] + ss[1]);
   // lanes past the last frame get phi = 0: nothing enters the statistics, nothing is stored
-  const float inv = ok ? __builtin_amdgcn_rcpf(ssum) : 0.f;
+  const float inv = (FULL || ok) ? __builtin_amdgcn_rcpf(ssum) : 0.f;
   const f32x2 inv2 = {inv, inv};
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
@@ -430,17 +451,19 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
 #ifdef BNPVI_ABLATE_NOSTORE
   if (ok && lg[0][0] + lg[0][1] == -123.f) {
 #else
-  if (ok) {
+  if (FULL || ok) {
 #endif
     float* prow_out = p.phi + n * p.Lp + 4 * kg;
 #pragma unroll
     for (int T = 0; T < NT; ++T)
       if (TV > 0 || T < tiles_valid)
-        *reinterpret_cast<float4*>(prow_out + kLT * T) = make_float4(lg[T][0], lg[T][1], lg[T][2], lg[T][3]);
+        store_phi4(prow_out + kLT * T, lg[T]);
   }
 }
 
-template <int DP, int NT, bool HARD, bool STATS>
+// FULL: every frame of the tile exists, a next tile is always prefetched (next_tile valid) and only
+// soft responsibilities are asked for -- the body is then straight-line code (see tile_distances).
+template <int DP, int NT, bool HARD, bool STATS, bool FULL = false>
 __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOperands& lo_, int64_t tile,
                                            int64_t next_tile, int64_t ntiles, int lane, int tiles_valid,
                                            float4 (&zA)[DP / 32], float4 (&zB)[DP / 32],
@@ -457,7 +480,7 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
 #else
   const float* prow = HARD ? nullptr : p.prior + (int64_t)vcur * p.Lp;
 #endif
-  const bool soft_only = !(HARD || p.logphi != nullptr || p.assign != nullptr);   // wave-uniform
+  const bool soft_only = FULL || !(HARD || p.logphi != nullptr || p.assign != nullptr);   // wave-uniform
   // The video index came with the previous tile's prefetch, so the prior entries are requested
   // BEFORE the MFMA block (with the next tile's Z rows and video index): their L2 round trip
   // runs under the MFMAs instead of in front of the epilogue.
@@ -467,15 +490,18 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
 #pragma unroll
       for (int T = 0; T < NT; ++T) pre[T] = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * (lane >> 4));
     }
-    if (!HARD && next_tile < ntiles) {
+    if (FULL || (!HARD && next_tile < ntiles)) {
       const int64_t n2 = next_tile * kFT + j;
       vcur = p.vid[n2 < p.N ? n2 : p.N - 1];
     }
   };
   f32x4 d2[NT];
-  tile_distances<DP, NT>(p.Z, p.ldz, tile * kFT, p.N, zA, zB, next_tile < ntiles ? next_tile * kFT : -1,
-                         lo_, lane, tiles_valid, p.L, d2, more_loads);
-  if (!soft_only)
+  tile_distances<DP, NT, decltype(more_loads), FULL>(
+      p.Z, p.ldz, tile * kFT, p.N, zA, zB, (FULL || next_tile < ntiles) ? next_tile * kFT : -1, lo_, lane,
+      tiles_valid, p.L, d2, more_loads);
+  if (FULL)
+    tile_epilogue_soft<NT, TV, STATS, true>(p, n, true, lane, tiles_valid, prow, pre, d2, s0, s2);
+  else if (!soft_only)
     tile_epilogue_generic<NT, HARD, STATS>(p, n, ok, lane, tiles_valid, prow, d2, s0, s2);
   else
     tile_epilogue_soft<NT, TV, STATS>(p, n, ok, lane, tiles_valid, prow, pre, d2, s0, s2);
@@ -538,6 +564,32 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
   if (tile < ntiles) {
     load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA0, zB0);
     if (!HARD) vcur0 = vid[tile * kFT + j < N ? tile * kFT + j : N - 1];
+  }
+  // Production path (soft responsibilities only, small trees): the whole tiles of the wave run in a
+  // loop whose body has no branch around a memory instruction -- the prefetch of the next tile is
+  // unconditional (the last iteration re-requests its own rows) -- so every s_waitcnt vmcnt the
+  // compiler places is exact: the wait for this tile's rows leaves the previous tile's phi stores
+  // in flight, the wait for the prior entries leaves the next tile's rows in flight.  With
+  // conditional loads / stores in the body the counts are merged over the branches and degrade to
+  // vmcnt(0): one exposed HBM round trip per tile (rocprofv3: 54 % of wave cycles in s_waitcnt).
+  if constexpr (!HARD && PF == 1 && NT <= 4) {
+    if (logphi == nullptr && assign == nullptr) {
+      const int64_t nfull = N / kFT;
+      if (tile < nfull) {
+        // clean entry state: nothing outstanding when the loop is entered
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));        // vmcnt(0)
+        while (tile < nfull) {
+          const int64_t nxt = tile + stride < nfull ? tile + stride : tile;
+          fused_tile<DP, NT, false, STATS, true>(p, lo_, tile, nxt, ntiles, lane, tiles_valid, zA0, zB0, vcur0, s0,
+                                                 s2);
+          tile += stride;
+        }
+        if (tile < ntiles) {            // the ragged last tile of the data set: fresh loads, generic body
+          load_ztile<DP>(Z, ldz, tile * kFT, N, lane, zA0, zB0);
+          vcur0 = vid[tile * kFT + j < N ? tile * kFT + j : N - 1];
+        }
+      }
+    }
   }
   if constexpr (PF == 2) {
     if (tile + stride < ntiles) {

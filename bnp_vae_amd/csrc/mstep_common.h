@@ -111,6 +111,15 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 __device__ __forceinline__ void dma16(const void* g, float* l) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux bit 1): for bytes this kernel reads once and
+// nothing reads again before they would be evicted anyway
+__device__ __forceinline__ void dma16_nt(const void* g, float* l) {
+#ifdef BNPVI_PHI_LOAD_PLAIN
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 0);
+#else
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 16, 0, 2);
+#endif
+}
 __device__ __forceinline__ void dma4(const void* g, float* l) {
   __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)l, 4, 0, 0);
 }

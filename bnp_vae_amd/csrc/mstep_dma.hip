@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
       const float* ga = phi_t + f0 * ldphi;
       const float* gb = z_t + f0 * ldz;
 #pragma unroll
-      for (int q = 0; q < 2 * TL; ++q) dma16(ga + (int64_t)(q * rowsA) * ldphi + offA, slot + q * 256);
+      for (int q = 0; q < 2 * TL; ++q) dma16_nt(ga + (int64_t)(q * rowsA) * ldphi + offA, slot + q * 256);
 #pragma unroll
       for (int q = 0; q < 2 * TD; ++q) dma16(gb + (int64_t)(q * rowsB) * ldz + offB, slot + Slot::kA + q * 256);
       dma4(vid + f0 + (lane & 15), slot + Slot::kA + Slot::kB);

@@ -3,8 +3,11 @@ ranking in /root/reference/src/create_hierarchy.py: nearest-leaf assignment (:82
 a leaf (:87-90), frames of an internal node = concatenation over its children (:44-49), ranking
 by ||alpha - z|| with a stable sort and truncation to K (:50-51).  Leaves are numbered
 depth-first where the reference uses the Python-2 order of a dict keyed by Node objects (address
-dependent, so unpinned).  Parity: pinned by a hand-computed case in tests/test_oracle_golden.py
-only -- the reference tool itself needs image files and is not run.
+dependent; under Python 3 it is insertion = depth-first order).  Parity: PINNED -- both reference tools
+(create_hierarchy.py and compute_acc_frame_avg_dynamic.py) were run unmodified in the build
+container on files in their own input formats by oracle/make_golden.py (offline_tools), and
+tests/test_oracle_golden.py replays this restatement against tests/golden/offline_tools.npz
+(assignments, vote table, path->class map, predictions, precision, per-node closest frames).
 """
 import numpy as np
 
@@ -101,4 +104,19 @@ def class_vote(root, z_train, train_labels, z_test, decay_factor=0.0):
                 min_idx = np.argmin(dist)
             path2class[i] = path2class[min_idx]
     predicted = [path2class[int(np.argmin(np.linalg.norm(alpha_values - z, axis=1)))] for z in z_test]
+    class_vote.last = dict(path_assignments=np.asarray(path_assignments), counts_total=counts_total,
+                           leaf_ids=leaf_ids)
     return path2class, np.asarray(predicted)
+
+
+def precision_percent(predicted, test_labels):
+    """The number the tool prints last (src/compute_acc_frame_avg_dynamic.py:131-146): correct
+    predictions over all frames whose predicted class is one of the 15 MED classes, in percent."""
+    predicted, test_labels = np.asarray(predicted), np.asarray(test_labels)
+    corr = (predicted == test_labels).astype(int)
+    aggr_corr = aggr_total = 0.0
+    for class_id in range(15):
+        idx = np.where(predicted == class_id)[0]
+        aggr_corr += np.sum(corr[idx])
+        aggr_total += len(idx)
+    return 100.0 * aggr_corr / aggr_total

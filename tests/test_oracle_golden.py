@@ -155,3 +155,72 @@ def test_class_vote_oracle_hand_case():
     assert list(p2c) == [0, 1, 0] and list(pred) == [0, 1]
     p2c, _ = class_vote(r, z, [0, 0, 1, 1, 0], z[:1], 1.0)        # decay 1: own votes + all 5 votes of the root:
     assert list(p2c) == [0, 1, 0]                                 # (6,2), (3,4), (3,2)
+
+
+def test_trajectory_config5_shape():
+    """BASELINE config-5 shape at fixture size (D = 128, num_splits = 4, splits and prunes in every epoch):
+    the oracle against what the real reference did (tests/golden/traj_config5_shape.npz)."""
+    from oracle.vi_oracle import drifting_latents
+    g = load("traj_config5_shape.npz")
+    m = meta(g)
+    fpv = list(g['fpv'])
+    N = int(g['N'])
+    vi = OracleVarInf(latent_code_size=m['D'], stdev_thr=m['thr'], num_splits=m['num_splits'])
+    ks = []
+    for ep in range(m['epochs']):
+        Z = drifting_latents(N, m['D'], m['ncomp'], m['seed'], ep, m['spread'])
+        want = sub(g, 'e%d_' % ep)
+        assert float(np.sum(Z.astype(np.float64))) == float(want['z_checksum'])
+        np.random.seed(13 + ep)
+        vi.update_variational_parameters(make_latent_dict(Z, fpv))
+        got = snapshot(vi)
+        assert list(got['ids']) == list(want['ids'])
+        np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
+        np.testing.assert_allclose(got['alpha'], want['alpha'], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(got['sigma'], want['sigma'], rtol=TOL, atol=TOL)
+        np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=TOL, atol=TOL, equal_nan=True)
+        np.testing.assert_allclose(got['phi'].sum(axis=0), want['phi_colsum'], rtol=1e-11)
+        np.testing.assert_allclose(got['phi'][:: max(1, N // 64)], want['phi_rows'], rtol=0, atol=TOL)
+        ks.append(len(got['ids']))
+    assert len(set(ks)) > 2 and max(ks) > 85          # the tree both grew past its initial 85 nodes and shrank
+
+
+def _offline_tree(g):
+    from oracle.vi_oracle import tree_from_arrays
+    return tree_from_arrays(g['tree_ids'], g['tree_parent'], g['tree_is_leaf'], g['tree_alpha'])
+
+
+@pytest.mark.parametrize("tag,decay,sparse", [("vote0_", 0.0, False), ("vote5_", 0.5, False),
+                                              ("vote0s_", 0.0, True), ("vote5s_", 0.5, True)])
+def test_class_vote_oracle_against_reference_tool(tag, decay, sparse):
+    """oracle/hierarchy_oracle.class_vote against the reference's compute_acc_frame_avg_dynamic.main run
+    unmodified (tests/golden/offline_tools.npz): assignments, vote table, path -> class, predictions and
+    the printed precision.  The sparse cases leave leaves without a vote (nearest-voted-leaf fallback)."""
+    from oracle.hierarchy_oracle import class_vote, precision_percent
+    g = load("offline_tools.npz")
+    nodes = _offline_tree(g)
+    n = int(g['n_sparse']) if sparse else len(g['z_train'])
+    p2c, pred = class_vote(nodes[0], g['z_train'][:n], g['train_labels'][:n], g['z_test'], decay)
+    assert class_vote.last['leaf_ids'] == list(g[tag + 'leaf_ids'])
+    np.testing.assert_array_equal(class_vote.last['path_assignments'], g[tag + 'path_assignments'])
+    np.testing.assert_array_equal(class_vote.last['counts_total'], g[tag + 'counts_total'])
+    np.testing.assert_array_equal(p2c, g[tag + 'path2class'])
+    np.testing.assert_array_equal(pred, g[tag + 'predicted'])
+    assert precision_percent(pred, g['test_labels']) == float(g[tag + 'precision'])
+    if sparse and decay == 0.0:
+        assert (g[tag + 'counts_total'].max(axis=1) == 0).any()
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_closest_frames_oracle_against_reference_tool(K):
+    """oracle/hierarchy_oracle.closest_frames against create_hierarchy.main run unmodified: the frames
+    it lists per node (its printed lines), ties included (duplicated training frames)."""
+    from oracle.hierarchy_oracle import closest_frames
+    g = load("offline_tools.npz")
+    nodes = _offline_tree(g)
+    assign, top = closest_frames(nodes[0], g['z_train'], K)
+    np.testing.assert_array_equal(assign, g['top%d_assign' % K])
+    by_id = {n.node_id: n for n in nodes}
+    assert sorted(by_id) == sorted(g['top%d_ids' % K])
+    for nid, frames in zip(g['top%d_ids' % K], g['top%d_frames' % K]):
+        assert top[by_id[str(nid)]] == [int(f) for f in frames if f >= 0], nid
