@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,17 @@ void set_error(const char* fmt, ...);
 constexpr int kTile = 32;          // MFMA 32x32 tile edge
 constexpr int kNumCU = 256;        // MI355X
 constexpr int kMaxLdsBytes = 160 * 1024;
+
+// Development switches (kernel-path overrides used by the tools/ scripts) exist only in builds made
+// with -DBNPVI_DEV_KNOBS; the shipped library never reads the environment on a launch path.
+inline const char* dev_getenv(const char* name) {
+#ifdef BNPVI_DEV_KNOBS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -97,7 +97,7 @@ static int run_streamed(const EstepArgs& a) {
   // operands of one chunk staged in LDS when they fit (8 waves share them), else read from L2
   constexpr int kStagedWaves = 8;
   const size_t lds = (size_t)NT * (DP / 32) * 2 * 64 * sizeof(f16x8) + (size_t)kLT * NT * sizeof(float);
-  const char* env = getenv("BNPVI_ESTEP_STREAM");                   // development switch: "l2"
+  const char* env = dev_getenv("BNPVI_ESTEP_STREAM");                   // development switch: "l2"
   const bool staged = lds <= (size_t)kMaxLdsBytes && !(env && strcmp(env, "l2") == 0);
   const int waves = staged ? kStagedWaves : kEWaves;
   const int per_cu = staged ? (int)((size_t)kMaxLdsBytes / lds) : 8;
@@ -175,7 +175,7 @@ static int launch_rows(const EstepArgs& a) {
 template <int DP, bool STATS>
 static int run_rows(const EstepArgs& a) {
   if constexpr (DP <= 64 && !STATS) {
-    const char* e = getenv("BNPVI_ROWS_PASSES");            // development switch: "2" forces two passes
+    const char* e = dev_getenv("BNPVI_ROWS_PASSES");            // development switch: "2" forces two passes
     const int chunks = ceil_div(a.tree->Lp, kLT * kRChunk);
     const bool one = !(e && e[0] == '2');
     if (one && chunks <= 2 && RowsLds<DP>::bytes(2 * kRChunk, STATS) <= (size_t)kMaxLdsBytes)
@@ -191,7 +191,7 @@ int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   constexpr int DP = BNPVI_DP;
   const int Lp = a.tree->Lp;
   const bool hard_stats = a.mode == BNPVI_ESTEP_HARD && a.estats != nullptr;
-  const char* force = getenv("BNPVI_ESTEP_PATH");         // development switch: "rows" | "fused"
+  const char* force = dev_getenv("BNPVI_ESTEP_PATH");         // development switch: "rows" | "fused"
   const bool want_rows = force ? strcmp(force, "rows") == 0 : Lp > 64;
   if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
     return a.estats ? run_rows<DP, true>(a) : run_rows<DP, false>(a);

@@ -171,6 +171,14 @@ __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
       }
     }
     if (lead_dim) {
+      // S0: fixed tree sum of the lane's 8 frames, accumulated in straight-line code AHEAD of the
+      // divergent video-boundary path (mstep_common.h, s0_accumulate: why)
+#pragma unroll
+      for (int a = 0; a < TL; ++a) {
+        const float t = ((r.a[a][0] + r.a[a][1]) + (r.a[a][2] + r.a[a][3])) +
+                        ((r.a[a][4] + r.a[a][5]) + (r.a[a][6] + r.a[a][7]));
+        s0_accumulate(s0[a], t);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if (do_mass) {
@@ -180,10 +188,7 @@ __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
           }
         }
 #pragma unroll
-        for (int a = 0; a < TL; ++a) {
-          s0[a] += r.a[a][e];
-          msum[a] += r.a[a][e];
-        }
+        for (int a = 0; a < TL; ++a) msum[a] += r.a[a][e];
       }
     }
   };
@@ -331,7 +336,7 @@ int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi,
   }
   if (!want_q) {
     // default path: LDS-DMA ring (mstep_dma.hip); BNPVI_MSTEP_PATH=reg | dma force the register-streamed / per-wave ring kernels
-    const char* force = getenv("BNPVI_MSTEP_PATH");
+    const char* force = dev_getenv("BNPVI_MSTEP_PATH");
     if (!(force && strcmp(force, "reg") == 0)) {
       if (!(force && strcmp(force, "dma") == 0)) {
         // large trees: workgroup-wide tiles (mstep_wide.hip)

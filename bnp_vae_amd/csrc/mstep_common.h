@@ -104,6 +104,37 @@ __device__ __forceinline__ void mac1(int k, const Frag& ah, const Frag& am, cons
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
 }
 
+// ---- S0 accumulation (mstep_dma.hip, mstep_wide.hip, mstep.hip)
+// History.  Written as `s0 += t` the compiler sinks the update behind the divergent video-boundary
+// path of the k-step and fuses the two leaf tiles into one packed add with swapped halves:
+//     v_pk_add_f32 v[2:3], v[2:3], v[4:5]            ; last level of the 8-frame tree sum
+//     s_cbranch_vccz .Ljoin                          ; TAKEN on the video-boundary path
+//   .Ljoin:
+//     v_pk_add_f32 v[14:15], v[14:15], v[2:3] op_sel:[0,1] op_sel_hi:[1,0]   ; S0 += t
+// In that form S0 of lanes 16-31 missed whole k-steps in about 1 of 1000 launches on MI355X (12 of
+// 10000 against 0 of 17500 with the update kept in front of the branch); S1 -- same registers,
+// through the MFMAs -- and the masses never did.  What the disassembly of the two builds (hipcc
+// -S, ROCm 7.2, with and without -DBNPVI_NO_S0_PIN) rules out: (1) an LDS refill race -- every
+// ds_read of a slot is followed by its s_waitcnt lgkmcnt(0) before the loop comes round to the
+// global_load_lds that refills the slot, and the counted vmcnt((R-1)*P) covers the pieces in issue
+// order, atomics of the boundary path included; (2) a wrong EXEC mask -- every s_and_saveexec of the
+// boundary path is matched by its s_or_b64 exec before the join, and the join block runs under the
+// loop's full mask; (3) a clobbered operand -- the boundary path writes v82-85, v89-95 only.  What
+// differs is only the instruction quoted above: a packed fp32 add with op_sel whose source is the
+// result of the packed add two instructions earlier, issued as the first VALU instruction after a
+// taken branch.  Packed fp32 instructions execute in four 16-lane passes; lanes 16-31 are the second
+// pass, so the data points at that second pass reading v[2:3] before the producer's second pass had
+// written it -- a forwarding / dependency-check hazard of this instruction pair that the compiler
+// does not pad (no s_nop is emitted there), not a logic error.  It is not proven beyond the A/B
+// count; the code below does not depend on the answer:
+//   * S0 is updated by ONE scalar-width v_add_f32 per leaf tile, written as inline asm, so it can be
+//     neither packed, nor given op_sel, nor moved across the branch;
+//   * it sits in straight-line code in front of the boundary path, behind the (also pinned) tree sum.
+// tests/test_gpu_round2.py::test_s0_is_exact_on_one_hot_responsibilities checks S0 bit for bit.
+__device__ __forceinline__ void s0_accumulate(float& s0, float t) {
+  asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(t));
+}
+
 // ---- LDS-DMA helpers (mstep_dma.hip, mstep_wide.hip)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;

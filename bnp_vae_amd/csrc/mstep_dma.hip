@@ -160,6 +160,9 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
     wait_vmcnt<0>();
 #else
     if (ks + R - 1 < nsteps) {
+      // every LDS read of the slot about to be refilled has returned (they all fed VALU work of the
+      // previous iteration); stated explicitly so the refill can never be scheduled above one
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       issue(ks + R - 1);
       wait_vmcnt<(R - 1) * P>();
     } else {
@@ -207,16 +210,7 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
 #pragma unroll
       for (int a = 0; a < TL; ++a) {
         t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
-        s0[a] += t[a];
-        // Keep the S0 update HERE, in straight-line code ahead of the divergent video-boundary
-        // path.  Left to the compiler it is sunk behind that path (packed add with op_sel right
-        // after the exec-mask restores and a taken branch), and there S0 of lanes 16-31 lost
-        // whole k-steps once in ~1000 launches on MI355X (S1, from the same registers through
-        // the MFMAs, never did): tools/mstress3.py, 12 of 10000 launches without the pin, 0 of
-        // 17500 with it.  -DBNPVI_NO_S0_PIN rebuilds the failing variant.
-#ifndef BNPVI_NO_S0_PIN
-        asm volatile("" : "+v"(s0[a]));
-#endif
+        s0_accumulate(s0[a], t[a]);            // mstep_common.h: why this is not `s0[a] += t[a]`
       }
       if (__builtin_expect(same_video, 1)) {
 #pragma unroll
@@ -314,12 +308,12 @@ static int run_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, in
   // 1.11 ms; 15 MB: 11.5 vs 13.4 us).  BNPVI_MSTEP_ORDER=<b>[r] | c overrides (development):
   // blocks of 2^b k-steps, r = backwards; c = contiguous chunks.
   static const int env_order = [] {
-    const char* e = getenv("BNPVI_MSTEP_ORDER");
+    const char* e = dev_getenv("BNPVI_MSTEP_ORDER");
     if (!e || !e[0]) return -2;
     return (e[0] >= '0' && e[0] <= '6') ? e[0] - '0' : -1;
   }();
   static const int env_rev = [] {
-    const char* e = getenv("BNPVI_MSTEP_ORDER");
+    const char* e = dev_getenv("BNPVI_MSTEP_ORDER");
     return (e && e[0] && e[1] == 'r') ? 1 : 0;
   }();
   const double bytes = (double)N * (ldphi + ldz) * sizeof(float);

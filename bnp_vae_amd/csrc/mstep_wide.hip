@@ -259,8 +259,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #pragma unroll
     for (int a = 0; a < TS; ++a) {
       t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
-      s0[a] += t[a];
-      asm volatile("" : "+v"(s0[a]));        // see mstep_dma.hip: keep the S0 update ahead of the divergent path
+      s0_accumulate(s0[a], t[a]);            // mstep_common.h: why this is not `s0[a] += t[a]`
     }
     if (__builtin_expect(same_video, 1)) {
 #pragma unroll
@@ -453,7 +452,7 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   // leaves one XCD a round behind), chunks of at most kMaxChunk frames (fp32 partial sums); long
   // chunks keep the fp64 slab traffic (gx L W 8 bytes, written and reduced) small.
   int rounds = 2;
-  if (const char* e = getenv("BNPVI_WIDE_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
+  if (const char* e = dev_getenv("BNPVI_WIDE_ROUNDS")) rounds = atoi(e) > 0 ? atoi(e) : rounds;
   int64_t gx = (int64_t)rounds * ctx->num_cu / ((int64_t)gy * gz);
   gx = gx >= 8 ? gx / 8 * 8 : (gx < 1 ? 1 : gx);
   if (ceil_div(N, gx) > kMaxChunk) gx = ceil_div(ceil_div(N, (int64_t)kMaxChunk), 8) * 8;

@@ -173,6 +173,10 @@ class DeviceVI(object):
             self.stats = self._empty((L, W), torch.float64)
         if want_mass and (self.mass is None or tuple(self.mass.shape) != (self.V, L)):
             self.mass = self._empty((self.V, L), torch.float64)
+        if self.N == 0 or self.V == 0:          # a rank without frames (fewer videos than ranks)
+            self.stats.zero_()
+            self.want_q = want_q
+            return self.stats
         check(lib.bnpvi_leaf_stats(self.ctx, _ptr(self.Z), self.Dp, _ptr(self.phi), self.tree.Lp,
                                    _ptr(self.vid), self.N, D, L, self.V, 1 if want_q else 0,
                                    _ptr(self.stats), _ptr(self.mass if want_mass else None),
@@ -196,6 +200,8 @@ class DeviceVI(object):
         K = self.tree.K
         if self.gamma is None or tuple(self.gamma.shape) != (self.V, K, 2):
             self.gamma = self._empty((self.V, K, 2), torch.float64)
+        if self.V == 0:
+            return
         check(lib.bnpvi_gamma_update(self.ctx, self.tree.handle, _ptr(self.mass), self.V,
                                      self.GAMMA, _ptr(self.gamma), self._stream()),
               "bnpvi_gamma_update")
@@ -209,6 +215,8 @@ class DeviceVI(object):
         if want_tables:
             on = self._empty((self.V, L), torch.float64)
             before = self._empty((self.V, L), torch.float64)
+        if self.V == 0:
+            return on, before
         check(lib.bnpvi_prior_table(self.ctx, self.tree.handle, _ptr(self.gamma), _ptr(self.sigma),
                                     self.V, self.sZ, _ptr(self.prior), _ptr(on), _ptr(before),
                                     self._stream()), "bnpvi_prior_table")
@@ -221,6 +229,8 @@ class DeviceVI(object):
             self.gamma = self._empty((self.V, K, 2), torch.float64)
         if self.prior is None or tuple(self.prior.shape) != (self.V, Lp):
             self.prior = self._empty((self.V, Lp), torch.float32)
+        if self.V == 0:
+            return
         check(lib.bnpvi_gamma_prior(self.ctx, self.tree.handle, _ptr(self.mass), _ptr(self.sigma), self.V,
                                     self.GAMMA, self.sZ, _ptr(self.gamma), _ptr(self.prior),
                                     self._stream()), "bnpvi_gamma_prior")
@@ -235,6 +245,10 @@ class DeviceVI(object):
         assign = self._empty((self.N,), torch.int32) if want_assign else None
         if want_stats and (self.estats is None or tuple(self.estats.shape) != (L, 2)):
             self.estats = self._empty((L, 2), torch.float64)
+        if self.N == 0:
+            if want_stats:
+                self.estats.zero_()
+            return logphi, assign
         check(lib.bnpvi_estep(self.ctx, self.tree.handle, _ptr(self.Z), self.Dp, _ptr(self.vid),
                               self.N, self.D, _ptr(self.alpha),
                               _ptr(self.prior if mode == _lib.ESTEP_SOFT else None), self.sZ,
@@ -267,6 +281,9 @@ class DeviceVI(object):
             self.gamma = self._empty((self.V, K, 2), torch.float64)
         if self.prior is None or tuple(self.prior.shape) != (self.V, Lp):
             self.prior = self._empty((self.V, Lp), torch.float32)
+        if self.V == 0:                           # no videos here: node parameters only
+            self.node_params()
+            return
         check(lib.bnpvi_params_prior(self.ctx, self.tree.handle, _ptr(self.stats), int(self.stats.shape[1]),
                                      self.D, self.sB, self.sZ, _ptr(self.alpha0), _ptr(self.alpha),
                                      _ptr(self.sigma), _ptr(self.mass), self.V, self.GAMMA, _ptr(self.gamma),
@@ -300,6 +317,8 @@ class DeviceVI(object):
                                             1 if k <= 1 else 0, _ptr(dist2), _ptr(best_row),
                                             _ptr(best_score), self._stream()), "bnpvi_kmeans_pass")
                 row, score = int(best_row.item()), float(best_score.item())
+                if k == 0:
+                    row, score = self._first_centre_among_saturated(col, row, score)
             else:
                 row, score = 0, -1.0
             if multi:
@@ -316,6 +335,26 @@ class DeviceVI(object):
                 rows.append(row)
             centres.append(centre[:self.D].to(torch.float64).cpu().numpy())
         return rows, np.asarray(centres)
+
+    def _first_centre_among_saturated(self, col, row, score):
+        """First k-means centre = arg-max of the leaf's responsibilities (src/var_inf.py:29-30).  On
+        well-separated data many frames have phi = 1 - c with c below fp32 resolution: in the fp32
+        matrix they all tie at exactly 1.0, while the reference's fp64 phi = 1 / (1 + c) still
+        orders them (c = the frame's responsibility mass on all OTHER leaves, which fp32 holds to
+        full relative precision).  For such ties the winner is re-picked the reference's way: largest
+        fp64 1 / (1 + c), first index among equals.  Returns (row, score) with the fp64 score."""
+        if score < 1.0 - 2e-7:
+            return row, score
+        wcol = self.phi[:, col]
+        tied = torch.nonzero(wcol == score).flatten()                     # ascending rows
+        if int(tied.numel()) <= 1:
+            return row, score
+        rows = self.phi.index_select(0, tied)[:, :self.tree.L].to(torch.float64)
+        c = rows.sum(dim=1) - rows[:, col]
+        phi64 = 1.0 / (1.0 + c)
+        best = phi64.max()
+        j = int(torch.nonzero(phi64 == best).flatten()[0])
+        return int(tied[j]), float(best)
 
     def remap_phi(self, new_L, src, scale):
         """phi_new[:, j] = scale[j] * phi_old[:, src[j]] (split / merge column surgery)."""

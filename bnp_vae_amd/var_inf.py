@@ -309,6 +309,8 @@ class VarInf(object):
                 for frameid in latent_codes[vidid]:
                     self.vidid_frameid_to_idx.append((vidid, frameid))
         rows = [z for vidid in latent_codes for z in latent_codes[vidid].values()]
+        if not rows:                 # a rank that holds no video (multi-rank, fewer videos than ranks)
+            return np.zeros((0, self.LATENT_CODE_SIZE), dtype=np.float32)
         return np.asarray(rows)
 
     # ================================================================== entry point
@@ -347,6 +349,7 @@ class VarInf(object):
     def _update(self, Z):
         if self.root is None:
             self._build_initial_tree()
+            self._replicate_initial_alpha()
             self._one_hot_init(Z)
         for _iteration in range(1):
             self.compute_sigma_alpha(Z)
@@ -375,6 +378,21 @@ class VarInf(object):
                 par.isLeafNode = False
                 par.children = cur[self.BF * i: self.BF * (i + 1)]
             prev = cur
+
+    def _replicate_initial_alpha(self):
+        """Multi-rank: the tree is replicated, so every rank must start from rank 0's draws of
+        Node.alpha (the process-local NumPy streams need not be seeded alike)."""
+        if not self._multi():
+            return
+        import torch
+        from . import dist as vdist
+        nodes = self._preorder()
+        dev = self._engine()
+        a = torch.from_numpy(np.asarray([n.alpha for n in nodes], dtype=np.float64)).to(dev.device)
+        vdist.broadcast_from(a, 0, self._group)
+        a = a.cpu().numpy()
+        for k, n in enumerate(nodes):
+            n.alpha = a[k].copy()
 
     def _one_hot_init(self, Z):
         """phi <- one-hot of the nearest leaf (src/var_inf.py:126-132), on the device."""

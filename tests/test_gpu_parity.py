@@ -185,6 +185,7 @@ def _regular_case(N, D, bf, levels, fpv, seed):
     (700, 130, 6, 4, [512]),          # L=1296 (5.06 leaf blocks of 256), D=130 -> 256: partial last leaf block
     (1800, 128, 8, 3, [256, 61]),     # L=512, D=128: one 512-leaf x 128-dim workgroup tile (mstep_wide.hip)
     (900, 256, 23, 2, [128]),         # L=529 (2.07 blocks of 256), D=256
+    (512, 256, 6, 5, [100, 57, 200]), # BASELINE config 4's exact tree (K=9331, L=7776, D=256), videos of unequal length
 ])
 def test_iteration_against_oracle(N, D, bf, levels, fpv):
     ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=7)
