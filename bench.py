@@ -2,19 +2,27 @@
 """Benchmark of the VI iteration (M-step -> gamma-step -> prior table -> E-step, the body of
 /root/reference/src/var_inf.py:135-137) on synthetic Gaussian-mixture latents.
 
-  python bench.py --gpus N --steps K --warmup W          (N=1 directly; N>1 under torchrun)
+  python bench.py --gpus N --steps K --warmup W
 
-A "step" is one full VI iteration over the rank's resident latents (Z, phi, video ids already
-in HBM).  Default workload = BASELINE.json configs[1]: N=1M frames, D=64, 8-ary tree with
-K=73 nodes / L=64 leaves, videos of 256 frames.  With N ranks every rank holds its own 1M
-frames (weak scaling) and the only collective is one fp64 all-reduce of the leaf statistics
-per iteration (RCCL).  Rank 0 prints ONE JSON line.
+N = 1 runs in this process.  N > 1: under a launcher (torch.distributed.run sets WORLD_SIZE) this
+process is one rank; from a bare shell the parent starts N fresh children itself -- before it
+imports torch or touches a GPU -- one rank per GPU over RCCL, and prints rank 0's JSON line.
+
+A "step" is one full VI iteration over the rank's resident latents (Z, phi, video ids already in
+HBM) plus the all-reduce of the split/merge statistics the drop-in issues after every E-step.
+Headline workload = BASELINE.json configs[1]: N=1M frames per rank, D=64, 8-ary tree with K=73
+nodes / L=64 leaves, videos of 256 frames (weak scaling: every rank holds its own 1M frames).  The
+same JSON line carries `config3_strong`: BASELINE configs[2] (16M frames in total, D=64, K=585)
+divided over the ranks -- the strong-scaling case of north_star's ">= 7x at 8 GPUs on N=16M".
+Collectives per step: one fp64 all-reduce of the L x (1+D) leaf statistics (the M-step) and one of
+the L x 2 split/merge statistics.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,9 +33,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
-    # name: (N per rank, D, branching, levels below root)   -- BASELINE.json configs / SURVEY.md section 0
+    # name: (N, D, branching, levels below root)   -- BASELINE.json configs / SURVEY.md section 0
     "config1": (60_000, 32, 5, 2),        # K=31,  L=25
-    "config2": (1_000_000, 64, 8, 2),     # K=73,  L=64   (headline, memory-bound E/M-step)
+    "config2": (1_000_000, 64, 8, 2),     # K=73,  L=64   (headline, memory-bound E/M-step; N per rank)
     "config3": (16_000_000, 64, 8, 3),    # K=585, L=512  (total N; divided over ranks)
     "config4": (4_000_000, 256, 6, 5),    # K=9331, L=7776 (total N; divided over ranks)
 }
@@ -56,41 +64,186 @@ def make_latents(torch, device, N, D, L, rank):
     mu = torch.from_numpy(np.random.RandomState(13).normal(scale=4.0, size=(L, D)).astype(np.float32)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(13 + 1000 * rank)
-    comp = torch.randint(0, L, (N,), generator=g, device=device)
-    Z = mu[comp] + torch.randn((N, D), generator=g, device=device, dtype=torch.float32)
+    Z = torch.empty((N, D), dtype=torch.float32, device=device)
+    step = 1 << 21                                   # bounded temporaries at 16M frames
+    for lo in range(0, N, step):
+        hi = min(N, lo + step)
+        comp = torch.randint(0, L, (hi - lo,), generator=g, device=device)
+        Z[lo:hi] = mu[comp] + torch.randn((hi - lo, D), generator=g, device=device, dtype=torch.float32)
     vid = (torch.arange(N, device=device) // FRAMES_PER_VIDEO).to(torch.int32)
     V = int((N + FRAMES_PER_VIDEO - 1) // FRAMES_PER_VIDEO)
     return Z, vid, V
 
 
-def cpu_baseline(D, bf, levels, sample_n):
-    """The reference-faithful CPU port (oracle with the reference's per-frame loop and
-    list.index lookups, single thread like the reference) on a bounded sample."""
+# ---------------------------------------------------------------------------------------------
+# CPU baseline (runs BEFORE this process touches the GPU, so forking worker processes is safe)
+def _oracle_iteration(args):
+    D, bf, levels, sample_n, faithful, seed = args
     from oracle.vi_oracle import OracleVarInf, make_latent_dict, gaussian_mixture
-    L = bf ** levels
-    Z = gaussian_mixture(sample_n, D, L, seed=13, spread=4.0)
+    Z = gaussian_mixture(sample_n, D, bf ** levels, seed=seed, spread=4.0)
     lc = make_latent_dict(Z, [FRAMES_PER_VIDEO])
-    out = {}
-    for faithful in (True, False):
-        np.random.seed(13)
-        vi = OracleVarInf(latent_code_size=D, branching=bf, levels=levels, faithful_loops=faithful)
-        Zm = vi.get_matrix_from_dict(lc)
-        vi.build_initial_tree()
-        vi.build_video_index()
-        vi.one_hot_init(Zm)
-        t0 = time.perf_counter()
-        vi.compute_sigma_alpha(Zm)
-        vi.compute_gamma()
-        vi.compute_phi(Zm)
-        out[faithful] = sample_n / (time.perf_counter() - t0)
+    np.random.seed(13)
+    vi = OracleVarInf(latent_code_size=D, branching=bf, levels=levels, faithful_loops=faithful)
+    Zm = vi.get_matrix_from_dict(lc)
+    vi.build_initial_tree()
+    vi.build_video_index()
+    vi.one_hot_init(Zm)
+    t0 = time.perf_counter()
+    vi.compute_sigma_alpha(Zm)
+    vi.compute_gamma()
+    vi.compute_phi(Zm)
+    return time.perf_counter() - t0, len(lc)
+
+
+def cpu_baseline(D, bf, levels, sample_n):
+    """The reference-faithful CPU port (oracle with the reference's per-frame loop and list.index
+    lookups, single thread like the reference) on a bounded sample; beside it the vectorised
+    NumPy oracle on one core and on every core of this box's share (one process per core, each
+    with its own shard of `sample_n` frames, as a sample-sharded CPU run would)."""
+    import multiprocessing as mp
+    t_faithful, nvid = _oracle_iteration((D, bf, levels, sample_n, True, 13))
+    t_vec, _ = _oracle_iteration((D, bf, levels, sample_n, False, 13))
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(16, os.cpu_count() or 1)
+    cores = max(1, min(cores, os.cpu_count() or 1))
+    t_all = None
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(cores) as pool:
+            t0 = time.perf_counter()
+            pool.map(_oracle_iteration, [(D, bf, levels, sample_n, False, 13 + i) for i in range(cores)])
+            t_all = time.perf_counter() - t0            # includes each worker's set-up: a lower bound on the rate
+    except Exception:
+        t_all = None
     return {
-        "value": out[True], "unit": "samples/s", "cores": 1, "kind": "port",
+        "value": sample_n / t_faithful, "unit": "samples/s", "cores": 1, "kind": "port",
         "sample": "first %d frames (%d videos) of the workload, one M+gamma+E iteration of "
-                  "oracle/vi_oracle.py with the reference's per-frame loop" % (sample_n, len(lc)),
-        "vectorized_value": out[False],
-        "vectorized_note": "same oracle with the per-frame loop vectorised (NumPy, %d host cores visible)"
-                           % (os.cpu_count() or 1),
+                  "oracle/vi_oracle.py with the reference's per-frame loop" % (sample_n, nvid),
+        "vectorized_value": sample_n / t_vec,
+        "vectorized_note": "same oracle with the per-frame loop vectorised (NumPy), ONE core",
+        "vectorized_all_cores_value": (cores * sample_n / t_all) if t_all else None,
+        "vectorized_all_cores": cores,
+        "vectorized_all_cores_note": "%d processes x %d frames each (sample-sharded), wall time incl. per-process set-up"
+                                     % (cores, sample_n),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+def launch_children(args):
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this parent has
+    not imported torch and never touches a GPU) and relay rank 0's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+class Runner(object):
+    """One rank's timing of one workload."""
+
+    def __init__(self, torch, dist, device, local_rank, rank, world, group, rehearsal):
+        self.torch, self.dist, self.device = torch, dist, device
+        self.local_rank, self.rank, self.world, self.group, self.rehearsal = local_rank, rank, world, group, rehearsal
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, cfg, N, steps, warmup, want_estats):
+        import ctypes as C
+        from bnp_vae_amd import _lib
+        from bnp_vae_amd.engine import DeviceVI
+        torch = self.torch
+        _n, D, bf, levels = CONFIGS[cfg]
+        N = (N // FRAMES_PER_VIDEO) * FRAMES_PER_VIDEO or N     # shards cut on video boundaries
+        parent, is_leaf = regular_tree(bf, levels)
+        K, L = len(parent), int(is_leaf.sum())
+        dev = DeviceVI(device=self.local_rank, group=self.group)
+        Z, vid, V = make_latents(torch, self.device, N, D, L, self.rank)
+        dev.set_latents(Z, vid, V)
+        del Z
+        alpha0 = np.random.RandomState(13).normal(size=(K, D))      # Node.__init__ draw, src/node.py:12
+        dev.set_tree(parent, is_leaf, alpha0, np.ones(K))
+        dev.default_gamma()
+        dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)            # phi_in = one-hot nearest leaf
+
+        def step():
+            dev.iteration(want_estats=want_estats)
+            if want_estats and self.world > 1:
+                dev.allreduce_estats()                               # what split_nodes / merge_nodes read
+
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+
+        # Kernel durations for the roofline: a second, UNTIMED run of the same steps with the library's
+        # HIP-event pairs around the two data-pass kernels (recorded on the launch stream; the event
+        # records cost a few microseconds per launch, so they stay out of the timed region above).
+        def read(which):
+            ms, cnt = C.c_double(), C.c_int()
+            _lib.check(_lib.lib.bnpvi_profile_read(dev.ctx, which, C.byref(ms), C.byref(cnt)))
+            return (ms.value / cnt.value) if cnt.value else float("nan")
+
+        _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 1))
+        for _ in range(steps):
+            step()
+        self.barrier()
+        e_ms, m_ms = read(0), read(1)
+        _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 0))
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if self.rehearsal else self.device)
+        if self.world > 1:
+            self.dist.all_reduce(tmax, op=self.dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+        # sanity of the state the timed loop left behind (cheap, outside the timed region)
+        rows = dev.phi[: min(N, 4096), :L].sum(dim=1)
+        assert torch.allclose(rows, torch.ones_like(rows), atol=1e-4), "phi rows do not sum to 1"
+        dev.close()
+        del dev
+        torch.cuda.empty_cache()
+
+        ms_per_step = elapsed / steps * 1e3
+        kern_bytes = N * 4.0 * (D + L)            # per launch: E reads Z + writes phi; M reads Z + phi
+        dom, dom_ms = ("estep", e_ms) if e_ms >= m_ms else ("mstep_stats", m_ms)
+        achieved = kern_bytes / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(pmc):
+            try:
+                rec = json.load(open(pmc)).get("%s:%s" % (cfg, dom))
+                if rec and rec.get("N") == N:
+                    traffic = rec["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        return {
+            "N": N, "D": D, "bf": bf, "K": K, "L": L, "V": V, "ms_per_step": ms_per_step,
+            "value": N * self.world / (elapsed / steps),
+            "allreduce_bytes_per_step": (L * (1 + D) * 8 + (L * 2 * 8 if want_estats else 0)) if self.world > 1 else 0,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_ms": dom_ms,
+                         "estep_ms": e_ms, "mstep_stats_ms": m_ms,
+                         "iteration_frac": N * 8.0 * (D + L) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        }
 
 
 def main():
@@ -104,132 +257,92 @@ def main():
     ap.add_argument("--no-estats", action="store_true",
                     help="skip the split/merge statistics epilogue of the E-step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the config3_strong sub-record")
     ap.add_argument("--cpu-sample", type=int, default=60_000)
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)"
-                  % (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
-    # Rehearsal on a one-GPU box (never the measured configuration): BNPVI_BENCH_REHEARSAL=1 puts
-    # every rank on cuda:0 and uses gloo for the collective, so the N>1 control flow can be run
-    # where RCCL (one device per rank) cannot.
-    rehearsal = world > 1 and os.environ.get("BNPVI_BENCH_REHEARSAL") == "1"
+
+    _n, D, bf, levels = CONFIGS[args.config]
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(D, bf, levels, args.cpu_sample)        # before torch / the GPU: it forks workers
+
+    import torch
+    import torch.distributed as dist
+
+    # Rehearsal on a box with fewer GPUs than ranks (never a measured configuration): every rank on
+    # cuda:0, gloo with host-staged collectives.  Forced with BNPVI_BENCH_REHEARSAL=1.
+    rehearsal = world > 1 and (os.environ.get("BNPVI_BENCH_REHEARSAL") == "1" or torch.cuda.device_count() < world)
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
+    backend = "none"
     if world > 1:
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
 
-    from bnp_vae_amd import _lib
-    from bnp_vae_amd.engine import DeviceVI
-
-    N, D, bf, levels = CONFIGS[args.config]
+    run = Runner(torch, dist, device, local_rank, rank, world, group, rehearsal)
+    want_estats = not args.no_estats
+    N = CONFIGS[args.config][0]
     scaling = "weak"
     if args.config in ("config3", "config4"):
         N = N // world                       # fixed total problem: strong scaling
         scaling = "strong"
     if args.frames:
         N = args.frames
-    N = (N // FRAMES_PER_VIDEO) * FRAMES_PER_VIDEO or N     # shards cut on video boundaries
-    parent, is_leaf = regular_tree(bf, levels)
-    K, L = len(parent), int(is_leaf.sum())
+    head = run.run(args.config, N, args.steps, args.warmup, want_estats)
 
-    dev = DeviceVI(device=local_rank, group=group)
-    Z, vid, V = make_latents(torch, device, N, D, L, rank)
-    dev.set_latents(Z, vid, V)
-    del Z
-    alpha0 = np.random.RandomState(13).normal(size=(K, D))      # Node.__init__ draw, src/node.py:12
-    dev.set_tree(parent, is_leaf, alpha0, np.ones(K))
-    dev.default_gamma()
-    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)            # phi_in = one-hot nearest leaf
-    want_estats = not args.no_estats
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        dev.iteration(want_estats=want_estats)
-    import ctypes as C
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        dev.iteration(want_estats=want_estats)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # Kernel durations for the roofline: a second, UNTIMED run of the same K steps with the
-    # library's HIP-event pairs around the two data-pass kernels (the event records cost a few
-    # microseconds per launch, so they stay out of the timed region above).
-    def read(which):
-        ms, cnt = C.c_double(), C.c_int()
-        _lib.check(_lib.lib.bnpvi_profile_read(dev.ctx, which, C.byref(ms), C.byref(cnt)))
-        return (ms.value / cnt.value) if cnt.value else float("nan")
-
-    _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 1))
-    for _ in range(args.steps):
-        dev.iteration(want_estats=want_estats)
-    barrier()
-    e_ms, m_ms = read(0), read(1)
-    _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 0))
-
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-
-    # sanity of the state the timed loop left behind (cheap, outside the timed region)
-    rows = dev.phi[: min(N, 4096), :L].sum(dim=1)
-    assert torch.allclose(rows, torch.ones_like(rows), atol=1e-4), "phi rows do not sum to 1"
+    strong = None
+    if args.config == "config2" and not args.no_config3 and not args.frames:
+        n3 = CONFIGS["config3"][0] // world
+        if rehearsal:
+            n3 = min(n3, 262_144)            # all ranks share one GPU's memory in a rehearsal
+        s3 = max(3, min(args.steps, 10))
+        rec = run.run("config3", n3, s3, min(args.warmup, 2), want_estats)
+        strong = {"workload": "config3: %d frames in total over %d rank(s) (%d per rank), D=%d, K=%d, L=%d"
+                              % (rec["N"] * world, world, rec["N"], rec["D"], rec["K"], rec["L"]),
+                  "frames_total": rec["N"] * world, "frames_per_rank": rec["N"], "steps": s3, "scaling": "strong",
+                  "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": "samples/s",
+                  "allreduce_bytes_per_step": rec["allreduce_bytes_per_step"], "roofline": rec["roofline"]}
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = N * world / (elapsed / args.steps)
-        kern_bytes = N * 4.0 * (D + L)            # per launch: E reads Z + writes phi; M reads Z + phi
-        dom, dom_ms = ("estep", e_ms) if e_ms >= m_ms else ("mstep_stats", m_ms)
-        achieved = kern_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(pmc):
-            try:
-                rec = json.load(open(pmc)).get("%s:%s" % (args.config, dom))
-                if rec and rec.get("N") == N:
-                    traffic = rec["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
         out = {
             "metric": "latent samples/sec per VI E+M iteration (whole node)",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value": head["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: N=%d frames/rank, D=%d, %d-ary tree K=%d nodes L=%d leaves, "
                                    "%d-frame videos (V=%d), Gaussian-mixture latents, estats=%s"
-                                   % (args.config, N, D, bf, K, L, FRAMES_PER_VIDEO, V, want_estats),
-                       "parallelism": "sample-sharded x%d, 1 fp64 all-reduce of L x (1+D) stats/iter" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_ms": dom_ms,
-                         "estep_ms": e_ms, "mstep_stats_ms": m_ms,
-                         "iteration_frac": N * 8.0 * (D + L) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                   % (args.config, head["N"], head["D"], head["bf"], head["K"], head["L"],
+                                      FRAMES_PER_VIDEO, head["V"], want_estats),
+                       "parallelism": "sample-sharded x%d; per step 1 fp64 all-reduce of L x (1+D) leaf statistics"
+                                      " + 1 of L x 2 split/merge statistics" % world,
+                       "collective_backend": backend, "rehearsal_on_one_gpu": bool(rehearsal),
+                       "allreduce_bytes_per_step": head["allreduce_bytes_per_step"]},
+            "roofline": head["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(D, bf, levels, min(args.cpu_sample, N))
+        if strong is not None:
+            out["config3_strong"] = strong
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

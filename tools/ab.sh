@@ -10,7 +10,7 @@ for lib in default bnp_vae_amd/variants/libbnpvi_*.so; do
   if [ "$lib" = default ]; then unset BNPVI_LIB; else export BNPVI_LIB=$PWD/$lib; fi
   echo "== $lib" >> $out
   timeout -k 10 120 python tools/kbench.py --only leaf_stats,estep,estep_stats,iteration --iters 30 "$@" >> $out 2>&1
-  timeout -k 10 120 python bench.py --steps 50 --warmup 10 --no-cpu-baseline 2>&1 | python -c "
+  timeout -k 10 120 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-config3 2>&1 | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):
