@@ -57,6 +57,7 @@ EXPORTS = {
     "bnpvi_tree_num_leaves": (_i, [_p]),
     "bnpvi_tree_leaf_nodes": (_i, [_p, _p]),
     "bnpvi_leaf_stats": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _p, _p, _p]),
+    "bnpvi_leaf_stats_noalloc": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i, _i, _i, _i, _p, _p, _p]),
     "bnpvi_node_params": (_i, [_p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p]),
     "bnpvi_gamma_update": (_i, [_p, _p, _p, _i, _d, _p, _p]),
     "bnpvi_gamma_remap": (_i, [_p, _p, _i, _p, _i, _i, _p, _d, _p]),

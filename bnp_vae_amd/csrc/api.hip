@@ -40,6 +40,23 @@ void Scratch::release() {
   bytes = 0;
 }
 
+int slab_workspace(bnpvi_ctx* ctx, size_t need, double** out) {
+  if (ctx->slab_override) {
+    if (need > ctx->slab_override_bytes) {
+      set_error("this launch needs %zu bytes of partial-sum workspace; the no-allocation entry point has %zu "
+                "(use the allocating entry point, or fewer frames / a smaller tree per call)",
+                need, ctx->slab_override_bytes);
+      return BNPVI_EINVAL;
+    }
+    *out = (double*)ctx->slab_override;
+    return BNPVI_OK;
+  }
+  int rc = ctx->slabs.ensure(need);
+  if (rc) return rc;
+  *out = (double*)ctx->slabs.ptr;
+  return BNPVI_OK;
+}
+
 bool KernelTimer::begin(hipStream_t s) {
   if (used >= kMax) return false;
   if ((int)ev.size() < 2 * (used + 1)) {
@@ -125,6 +142,13 @@ int bnpvi_ctx_create(int device, bnpvi_ctx** out) {
   bnpvi_ctx* c = new bnpvi_ctx();
   c->device = device;
   c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : kNumCU;
+  // set-up for bnpvi_leaf_stats_noalloc: this device's copy of the static scratch array, resolved
+  // here (device current) so that the entry point itself never has to
+  int rc = static_scratch_address(&c->static_scratch, &c->static_scratch_bytes);
+  if (rc) {
+    delete c;
+    return rc;
+  }
   *out = c;
   return BNPVI_OK;
 }

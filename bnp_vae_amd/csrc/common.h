@@ -98,6 +98,13 @@ struct bnpvi_ctx {
   int ops_D = 0;
   // per-video mass buffer that bnpvi_params_prior left zeroed (bnpvi_leaf_stats skips its memset)
   const double* mass_clean = nullptr;
+  // this device's address of the static no-allocation scratch array (noalloc.hip), resolved once in
+  // bnpvi_ctx_create; while slab_override is set the statistics kernels put their partial-sum
+  // slabs there instead of in `slabs` (bnpvi_leaf_stats_noalloc)
+  void* static_scratch = nullptr;
+  size_t static_scratch_bytes = 0;
+  void* slab_override = nullptr;
+  size_t slab_override_bytes = 0;
 };
 
 struct bnpvi_tree {
@@ -158,6 +165,20 @@ int launch_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out,
 
 int launch_gamma_remap(bnpvi_ctx* ctx, const double* in, int K_old, double* out, int K_new, int V,
                        const int32_t* src_host, double gamma_hyper, hipStream_t s);
+
+// Partial-sum slab workspace of one statistics launch: the context's grow-only buffer, or -- inside
+// an entry point that may not allocate -- the region that entry point provides (an error when the
+// launch needs more than it holds).
+int slab_workspace(bnpvi_ctx* ctx, size_t need, double** out);
+// Most slabs of `slab_bytes` each a launch may use (unbounded with the context's own buffer).  A
+// launcher that would use more frames its waves' chunks longer instead, up to kMaxChunk frames.
+inline int64_t slab_cap(const bnpvi_ctx* ctx, size_t slab_bytes) {
+  if (!ctx->slab_override) return INT64_MAX;
+  return (int64_t)(ctx->slab_override_bytes / (slab_bytes ? slab_bytes : 1));
+}
+
+// noalloc.hip: address of the static scratch array on the CURRENT device (hipGetSymbolAddress)
+int static_scratch_address(void** ptr, size_t* bytes);
 
 // out[e] = sum_g slab[g][e], g ascending within 8 interleaved groups, groups combined in order
 // (fixed summation tree => bit-reproducible)

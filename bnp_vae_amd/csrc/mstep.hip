@@ -300,12 +300,18 @@ static int run_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, 
   chunk = (chunk + kKStep - 1) / kKStep * kKStep;
   if (chunk < 4 * kKStep) chunk = 4 * kKStep;
   if (chunk > kMaxChunk) chunk = kMaxChunk;
-  const int64_t gx = ceil_div(N, chunk * kStatWaves);
+  int64_t gx = ceil_div(N, chunk * kStatWaves);
+  const int64_t cap = slab_cap(ctx, (size_t)L * W * sizeof(double));
+  if (gx > cap && cap >= 1) {          // bounded workspace: fewer workgroups with longer chunks
+    chunk = (ceil_div(N, cap * kStatWaves) + kKStep - 1) / kKStep * kKStep;
+    if (chunk <= kMaxChunk) gx = ceil_div(N, chunk * kStatWaves);
+  }
   const int64_t blocks = ceil_div(gx, 8) * 8 * gy * gz;
   BNPVI_REQUIRE(gx >= 1 && blocks < (int64_t(1) << 31), "leaf_stats: grid of %lld workgroups",
                 (long long)blocks);
   const size_t slab_bytes = (size_t)gx * L * W * sizeof(double);
-  int rc = ctx->slabs.ensure(slab_bytes);
+  double* slab_ws = nullptr;
+  int rc = slab_workspace(ctx, slab_bytes, &slab_ws);
   if (rc) return rc;
   constexpr int NQ = Q ? 2 : 1;
   const size_t lds = (size_t)(TL * TD * NQ * 16 * 64 + TL * 32) * sizeof(double);
@@ -314,11 +320,11 @@ static int run_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, 
     BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kStatWaves * 64), lds, s, Z, ldz, phi, ldphi, vid,
-                     N, D, Dp, L, chunk, (double*)ctx->slabs.ptr, W, mass, (int)gx, gy, gz);
+                     N, D, Dp, L, chunk, slab_ws, W, mass, (int)gx, gy, gz);
   if (timed) ctx->timer[BNPVI_PROF_MSTEP].end(s);
   BNPVI_LAUNCH_CHECK();
   const int64_t elems = (int64_t)L * W;
-  return launch_slab_reduce((const double*)ctx->slabs.ptr, (int)gx, elems, stats, s);
+  return launch_slab_reduce(slab_ws, (int)gx, elems, stats, s);
 }
 
 int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,

@@ -325,20 +325,29 @@ static int run_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, in
   chunk = (chunk + unit - 1) / unit * unit;
   if (chunk < 4 * kKStep) chunk = (4 * kKStep + unit - 1) / unit * unit;
   if (chunk > kMaxChunk) chunk = kMaxChunk / unit * unit;
-  const int64_t gx = ceil_div(N, chunk * kDmaWaves);
+  int64_t gx = ceil_div(N, chunk * kDmaWaves);
+  const int64_t cap = slab_cap(ctx, (size_t)L * W * sizeof(double));
+  if (gx > cap && cap >= 1) {          // bounded workspace: fewer workgroups with longer chunks
+    const int64_t c2 = (ceil_div(N, cap * kDmaWaves) + unit - 1) / unit * unit;
+    if (c2 <= kMaxChunk) {
+      chunk = c2;
+      gx = ceil_div(N, chunk * kDmaWaves);
+    }
+  }
   const int64_t blocks = ceil_div(gx, 8) * 8 * gy * gz;
   BNPVI_REQUIRE(gx >= 1 && blocks < (int64_t(1) << 31), "leaf_stats: grid of %lld workgroups", (long long)blocks);
-  int rc = ctx->slabs.ensure((size_t)gx * L * W * sizeof(double));
+  double* slab_ws = nullptr;
+  int rc = slab_workspace(ctx, (size_t)gx * L * W * sizeof(double), &slab_ws);
   if (rc) return rc;
   auto kern = leaf_stats_dma_kernel<TL, TD, R>;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kDmaWaves * 64), lds, s, Z, ldz, phi, ldphi, vid, N, D, L,
-                     chunk, (double*)ctx->slabs.ptr, W, mass, (int)gx, gy, gz, order, rev);
+                     chunk, slab_ws, W, mass, (int)gx, gy, gz, order, rev);
   if (timed) ctx->timer[BNPVI_PROF_MSTEP].end(s);
   BNPVI_LAUNCH_CHECK();
-  return launch_slab_reduce((const double*)ctx->slabs.ptr, (int)gx, (int64_t)L * W, stats, s);
+  return launch_slab_reduce(slab_ws, (int)gx, (int64_t)L * W, stats, s);
 }
 
 #ifndef BNPVI_DMA_RING

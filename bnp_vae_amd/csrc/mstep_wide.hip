@@ -460,18 +460,27 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   chunk = (chunk + kKStep - 1) / kKStep * kKStep;
   if (chunk < 8 * kKStep) chunk = 8 * kKStep;
   gx = ceil_div(N, chunk);
+  const int64_t cap = slab_cap(ctx, (size_t)L * W * sizeof(double));
+  if (gx > cap && cap >= 1) {          // bounded workspace: fewer workgroups with longer chunks
+    const int64_t c2 = (ceil_div(N, cap) + kKStep - 1) / kKStep * kKStep;
+    if (c2 <= kMaxChunk) {
+      chunk = c2;
+      gx = ceil_div(N, chunk);
+    }
+  }
   const int64_t blocks = ceil_div(gx, 8) * 8 * gy * gz;
   BNPVI_REQUIRE(blocks < (int64_t(1) << 31), "leaf_stats: grid of %lld workgroups", (long long)blocks);
-  int rc = ctx->slabs.ensure((size_t)gx * L * W * sizeof(double));
+  double* slab_ws = nullptr;
+  int rc = slab_workspace(ctx, (size_t)gx * L * W * sizeof(double), &slab_ws);
   if (rc) return rc;
   auto kern = leaf_stats_wide_kernel<LBW, DBW, TL, TD>;
   BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWideWaves * 64), lds, s, Z, ldz, phi, ldphi, vid, N, D, L,
-                     chunk, (double*)ctx->slabs.ptr, W, mass, (int)gx, gy, gz);
+                     chunk, slab_ws, W, mass, (int)gx, gy, gz);
   if (timed) ctx->timer[BNPVI_PROF_MSTEP].end(s);
   BNPVI_LAUNCH_CHECK();
-  return launch_slab_reduce((const double*)ctx->slabs.ptr, (int)gx, (int64_t)L * W, stats, s);
+  return launch_slab_reduce(slab_ws, (int)gx, (int64_t)L * W, stats, s);
 }
 
 int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,

@@ -94,6 +94,21 @@ int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* p
                      int ldphi, const int32_t* vid_dev, int64_t N, int D, int L, int V,
                      int want_q, double* stats_dev, double* mass_dev, void* stream);
 
+/* ---- the same data pass for callers that cannot allocate ----------------------------------
+ * No counterpart in the reference.  For callers that cannot call hipMalloc: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation.  Same arguments, kernels and
+ * results (bit for bit) as bnpvi_leaf_stats, but the partial-sum slabs of the launch live in a
+ * static device array of the library (32 MiB per GPU, held until the process ends) instead of the
+ * context's grow-only workspace, and the call makes no hipMalloc / hipFree / allocating library
+ * call.  A launch that needs more than the array holds (workgroups x L x (1 + D (+ D)) doubles;
+ * config 2 with 1M frames needs 16.3 MB) is rejected with BNPVI_EINVAL and a message naming both
+ * sizes.  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two contexts, two threads) race -- serialise them.  The context must have been created with
+ * bnpvi_ctx_create (it resolves the array's address on its device). */
+int bnpvi_leaf_stats_noalloc(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* phi_dev,
+                             int ldphi, const int32_t* vid_dev, int64_t N, int D, int L, int V,
+                             int want_q, double* stats_dev, double* mass_dev, void* stream);
+
 /* ---- M-step node update: src/var_inf.py:265-297 (post-order Gauss-Seidel) --------------
  * sigma[k] : leaf  sB + sZ*S0 ; internal (1+#children)*sB
  * alpha[k] : leaf  (alpha_old[parent]*sB + sZ*S1)/sigma ; internal
