@@ -431,6 +431,9 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
           float* tb = phi + row0 * Lp + kLT * T;
           float* lb = logphi ? logphi + row0 * Lp + kLT * T : nullptr;
           if (full) {
+#ifdef BNPVI_ROWS_ABLATE_NOSTORE
+            if (pv[t][0][0] == -123.f)
+#endif
 #pragma unroll
             for (int r = 0; r < 4; ++r) tb[voff[r]] = pv[t][r >> 1][r & 1];
           } else {
