@@ -34,7 +34,7 @@ template <int DP>
 struct RowsLds {
   static size_t bytes(int NTp, bool stats) {
     return (size_t)NTp * (DP / 32) * 2 * 64 * 16 + (size_t)kLT * NTp * 4 +
-           (stats ? (size_t)kLT * NTp * 8 : 0);
+           (stats ? (size_t)kLT * NTp * 16 : 0);
   }
 };
 
@@ -58,14 +58,17 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   f16x8* a_lds = reinterpret_cast<f16x8*>(smem_raw);                    // [NTp*S*2*64]
   float* aa_lds = reinterpret_cast<float*>(a_lds + (size_t)NTp * S * 2 * 64);   // [16*NTp]
-  float* st_lds = aa_lds + kLT * NTp;                                   // [16*NTp][2] (STATS)
+  // [16*NTp][2] (STATS), fp64: the waves of the workgroup add their per-(tile, leaf tile) partial sums with
+  // LDS fp64 atomics, whose order varies from run to run -- in fp64 that moves the result by ~1e-16
+  // relative (fp32 atomics moved it by ~1e-5, and the split / merge decisions sit on these sums)
+  double* st_lds = reinterpret_cast<double*>(aa_lds + kLT * NTp);
   const int tiles_valid = Lp / kLT;
 
   for (int e = threadIdx.x; e < NTp * S * 2 * 64; e += blockDim.x)
     a_lds[e] = e < tiles_valid * S * 2 * 64 ? apack[e] : f16x8{0, 0, 0, 0, 0, 0, 0, 0};
   for (int e = threadIdx.x; e < kLT * NTp; e += blockDim.x) aa_lds[e] = e < Lp ? aavec[e] : 0.f;
   if (STATS)
-    for (int e = threadIdx.x; e < 2 * kLT * NTp; e += blockDim.x) st_lds[e] = 0.f;
+    for (int e = threadIdx.x; e < 2 * kLT * NTp; e += blockDim.x) st_lds[e] = 0.0;
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -416,8 +419,8 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
           const float a0 = cols4_sum(s0p[0] + s0p[1]);
           const float a2 = cols4_sum(s2p[0] + s2p[1]);
           if (kg == 0 && leaf < L) {
-            atomicAdd(&st_lds[2 * leaf], a0);
-            atomicAdd(&st_lds[2 * leaf + 1], a2);
+            atomicAdd(&st_lds[2 * leaf], (double)a0);
+            atomicAdd(&st_lds[2 * leaf + 1], (double)a2);
           }
         }
       }
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
             if (pv[t][0][0] == -123.f)
 #endif
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tb[voff[r]] = pv[t][r >> 1][r & 1];
+            for (int r = 0; r < 4; ++r) tb[voff[r]] = pv[t][r >> 1][r & 1];   // (non-temporal dword stores: +11 %)
           } else {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -454,7 +457,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
   if (STATS) {
     __syncthreads();
     double* out = eslab + (int64_t)blockIdx.x * 2 * L;
-    for (int e = threadIdx.x; e < 2 * L; e += blockDim.x) out[e] = (double)st_lds[e];
+    for (int e = threadIdx.x; e < 2 * L; e += blockDim.x) out[e] = st_lds[e];
   }
 }
 
