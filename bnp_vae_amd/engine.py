@@ -301,7 +301,10 @@ class DeviceVI(object):
     def kmeans_seed(self, col, num_centres):
         """Weighted farthest-point seeding on phi column `col` (src/var_inf.py:23-36).
 
-        Returns the chosen row indices (single process / rank-local frames)."""
+        Returns (chosen rows -- global indices under a process group --, centres (num_centres, D) fp64).
+        Single process: the passes are chained on the device (the arg-max row feeds the next pass's
+        centre through a device gather); the host synchronises twice per call -- after the first
+        centre, whose saturated-tie rule needs the score, and once at the end for the rows."""
         N = self.N
         multi = vdist.world_size(self.group) > 1
         dist2 = self._empty((max(N, 1),), torch.float32)
@@ -309,19 +312,20 @@ class DeviceVI(object):
         best_score = torch.zeros((1,), dtype=torch.float32, device=self.device)
         centre = torch.zeros((self.Dp,), dtype=torch.float32, device=self.device)
         wptr = C.c_void_p(self.phi.data_ptr() + 4 * col)
-        rows, centres = [], []
+        rows, row_t, centres = [], [], []
         for k in range(num_centres):
             if N > 0:
                 check(lib.bnpvi_kmeans_pass(self.ctx, _ptr(self.Z), self.Dp, N, self.D, wptr,
                                             int(self.phi.shape[1]), _ptr(centre if k > 0 else None),
                                             1 if k <= 1 else 0, _ptr(dist2), _ptr(best_row),
                                             _ptr(best_score), self._stream()), "bnpvi_kmeans_pass")
-                row, score = int(best_row.item()), float(best_score.item())
-                if k == 0:
-                    row, score = self._first_centre_among_saturated(col, row, score)
-            else:
-                row, score = 0, -1.0
             if multi:
+                if N > 0:
+                    row, score = int(best_row.item()), float(best_score.item())
+                    if k == 0:
+                        row, score = self._first_centre_among_saturated(col, row, score)
+                else:
+                    row, score = 0, -1.0
                 # arg-max over ranks: (score, global row), lowest row wins ties (np.argmax).  With
                 # all-zero scores every rank reports its local row 0, so global row 0 wins (the
                 # uniform fallback of normalize()); empty ranks (score -1) lose.
@@ -330,10 +334,19 @@ class DeviceVI(object):
                     centre.copy_(self.Z[grow - self.row_offset])
                 vdist.broadcast_from(centre, owner, self.group)
                 rows.append(grow)
-            else:
-                centre.copy_(self.Z[row])
-                rows.append(row)
-            centres.append(centre[:self.D].to(torch.float64).cpu().numpy())
+                centres.append(centre[:self.D].to(torch.float64).cpu().numpy())
+                continue
+            if k == 0:
+                row, score = int(best_row.item()), float(best_score.item())
+                row2, _ = self._first_centre_among_saturated(col, row, score)
+                if row2 != row:
+                    best_row.fill_(row2)
+            centre.copy_(self.Z.index_select(0, best_row)[0])           # device gather: no host round trip
+            row_t.append(best_row.clone())
+        if not multi:
+            rt = torch.cat(row_t)
+            rows = [int(r) for r in rt.cpu().numpy()]
+            return rows, self.Z.index_select(0, rt)[:, :self.D].to(torch.float64).cpu().numpy()
         return rows, np.asarray(centres)
 
     def _first_centre_among_saturated(self, col, row, score):
@@ -341,20 +354,22 @@ class DeviceVI(object):
         well-separated data many frames have phi = 1 - c with c below fp32 resolution: in the fp32
         matrix they all tie at exactly 1.0, while the reference's fp64 phi = 1 / (1 + c) still
         orders them (c = the frame's responsibility mass on all OTHER leaves, which fp32 holds to
-        full relative precision).  For such ties the winner is re-picked the reference's way: largest
-        fp64 1 / (1 + c), first index among equals.  Returns (row, score) with the fp64 score."""
+        full relative precision).  When the fp32 maximum is saturated the winner is re-picked the
+        reference's way: largest fp64 1 / (1 + c), first index among equals.  c comes from two strided
+        fp64 row sums over the other columns (no gather of the tied rows, no cancellation).
+        Returns (row, fp64 score)."""
         if score < 1.0 - 2e-7:
             return row, score
-        wcol = self.phi[:, col]
-        tied = torch.nonzero(wcol == score).flatten()                     # ascending rows
-        if int(tied.numel()) <= 1:
-            return row, score
-        rows = self.phi.index_select(0, tied)[:, :self.tree.L].to(torch.float64)
-        c = rows.sum(dim=1) - rows[:, col]
+        L = self.tree.L
+        c = torch.zeros((self.N,), dtype=torch.float64, device=self.device)
+        if col > 0:
+            c += self.phi[:, :col].sum(dim=1, dtype=torch.float64)
+        if col + 1 < L:
+            c += self.phi[:, col + 1:L].sum(dim=1, dtype=torch.float64)
         phi64 = 1.0 / (1.0 + c)
         best = phi64.max()
-        j = int(torch.nonzero(phi64 == best).flatten()[0])
-        return int(tied[j]), float(best)
+        first = torch.nonzero(phi64 == best).flatten()[0]
+        return int(first), float(best)
 
     def remap_phi(self, new_L, src, scale):
         """phi_new[:, j] = scale[j] * phi_old[:, src[j]] (split / merge column surgery)."""

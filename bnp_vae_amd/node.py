@@ -19,18 +19,53 @@ class Node(object):
         self.node_id = node_id
         self.isLeafNode = True
         self.parent = parent
+        self._owner = None          # VarInf that holds the device state
         # same draw from the global NumPy stream as src/node.py:12 (keeps seeded runs aligned)
-        self.alpha = np.random.normal(size=LATENT_CODE_SIZE)
-        self.sigmasqr_inv = 1.0
+        self._alpha = np.random.normal(size=LATENT_CODE_SIZE)
+        self._sigmasqr_inv = 1.0
         self.children = []
         self._num_vids = num_vids
         self._num_frames = num_frames
         self._gamma_hyper = GAMMA
-        self._owner = None          # VarInf that holds the device state
         self._phi_host = None       # host value (authoritative when not None)
         self._phi_dev = None        # (generation, column, scale) into the owner's device phi
         self._gamma_host = _DEFAULT  # host value, None (root-as-leaf), or _DEFAULT
         self._gamma_dev = None      # (generation, node row) into the owner's device gamma
+
+    # ------------------------------------------------------------------ alpha / sigmasqr_inv
+    # Plain host values, as in the reference -- but after an M-step the owner's device copy is newer; it
+    # is downloaded (all nodes at once) the first time anybody looks, not after every call.
+    @property
+    def alpha(self):
+        o = self.__dict__.get('_owner')
+        if o is not None and o._params_stale:
+            o._pull_params()
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, value):
+        o = self.__dict__.get('_owner')
+        if o is not None:
+            if o._params_stale:
+                o._pull_params()
+            o._host_params_ver += 1
+        self._alpha = value
+
+    @property
+    def sigmasqr_inv(self):
+        o = self.__dict__.get('_owner')
+        if o is not None and o._params_stale:
+            o._pull_params()
+        return self._sigmasqr_inv
+
+    @sigmasqr_inv.setter
+    def sigmasqr_inv(self, value):
+        o = self.__dict__.get('_owner')
+        if o is not None:
+            if o._params_stale:
+                o._pull_params()
+            o._host_params_ver += 1
+        self._sigmasqr_inv = value
 
     # ------------------------------------------------------------------ phi
     @property
@@ -78,6 +113,7 @@ class Node(object):
     # tools, which read .parent/.isLeafNode/.children/.alpha/.node_id.  Device-backed values
     # are materialised; the owner reference is dropped.
     def __getstate__(self):
+        self.alpha                   # refresh the host values if the device copy is newer
         d = dict(self.__dict__)
         keep_phi = True if self._owner is None else self._owner.pickle_phi
         d['_phi_host'] = self.phi if keep_phi else None
@@ -90,6 +126,9 @@ class Node(object):
 
     def __setstate__(self, d):
         self.__dict__.update(d)
+        if 'alpha' in self.__dict__:                 # pickles written before alpha became a property
+            self._alpha = self.__dict__.pop('alpha')
+            self._sigmasqr_inv = self.__dict__.pop('sigmasqr_inv', 1.0)
         if self.__dict__.get('_gamma_host', _DEFAULT) is not None and \
                 not isinstance(self.__dict__.get('_gamma_host'), np.ndarray):
             self._gamma_host = _DEFAULT

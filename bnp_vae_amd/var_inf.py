@@ -74,6 +74,16 @@ class VarInf(object):
         self._estats_alpha = None
         self._fpos = None
         self._fpos_key = None
+        self._params_stale = False   # device alpha / sigma newer than the Nodes' host values
+        self._host_params_ver = 0    # bumped whenever a Node's alpha / sigmasqr_inv is assigned
+        self._dev_params_ver = -1    # value of _host_params_ver the device copy was uploaded at
+        self._trusted = 0            # > 0 inside _update: the flattened tree is re-derived only when flagged
+        self._struct_dirty = True
+        self._dev_alpha_ver = 0      # bumped whenever the device alpha / sigma change
+        self._phi_synced = False     # device phi holds exactly the current leaves' columns, in order
+        self._gamma_synced = False   # same for the device gamma rows
+        self._phi_all_dev = -1       # generation at which every leaf was pointed at its device column
+        self._gamma_all_dev = -1
 
     # ================================================================== helpers
     def _log(self, *a):
@@ -160,15 +170,26 @@ class VarInf(object):
         return dev
 
     def _ensure_tree(self):
-        """Flatten the Node graph (pre-order) and rebuild the device tree if it changed."""
+        """Flatten the Node graph (pre-order) and rebuild the device tree if it changed.
+
+        A caller may have rearranged the Node graph by hand between calls (tests, tools), so the
+        public methods re-derive the flattening every time; inside one `_update` only split_nodes /
+        merge_nodes change it and they say so (`_struct_dirty`), which saves ~8 walks over all K nodes
+        per call.  Host alpha / sigma are uploaded only when a Node was assigned since the last upload."""
         dev = self._engine()
+        if self._trusted and not self._struct_dirty and self._sig is not None:
+            if self._dev_params_ver != self._host_params_ver:
+                self._push_params()
+            return dev
         nodes = self._preorder()
         sig = tuple((id(n), bool(n.isLeafNode)) for n in nodes)
         changed = sig != self._sig
-        index = {id(n): i for i, n in enumerate(nodes)}
-        alpha = np.asarray([np.asarray(n.alpha, dtype=np.float64) for n in nodes])
-        sigma = np.asarray([float(n.sigmasqr_inv) for n in nodes], dtype=np.float64)
         if changed:
+            if self._params_stale:
+                self._pull_params()              # the old flattening's device values, before it goes
+            index = {id(n): i for i, n in enumerate(nodes)}
+            alpha = np.asarray([np.asarray(n._alpha, dtype=np.float64) for n in nodes])
+            sigma = np.asarray([float(n._sigmasqr_inv) for n in nodes], dtype=np.float64)
             parent = np.asarray([-1 if n.parent is None else index[id(n.parent)] for n in nodes],
                                 dtype=np.int32)
             is_leaf = np.asarray([1 if n.isLeafNode else 0 for n in nodes], dtype=np.uint8)
@@ -180,19 +201,36 @@ class VarInf(object):
             self._estats_key = None
             for n in nodes:
                 n._owner = self
+            self._dev_params_ver = self._host_params_ver
+            self._dev_alpha_ver += 1
         else:
-            import torch
-            dev.alpha.copy_(torch.from_numpy(alpha))
-            dev.sigma.copy_(torch.from_numpy(sigma))
+            # public methods called directly: a caller may also have edited a Node's alpha IN PLACE
+            self._push_params()
+        self._struct_dirty = False
         return dev
 
+    def _push_params(self):
+        """Host alpha / sigma of the flattened nodes -> device (a Node was assigned)."""
+        import torch
+        dev = self._dev
+        if self._params_stale:
+            self._pull_params()
+        alpha = np.asarray([np.asarray(n._alpha, dtype=np.float64) for n in self._nodes])
+        sigma = np.asarray([float(n._sigmasqr_inv) for n in self._nodes], dtype=np.float64)
+        dev.alpha.copy_(torch.from_numpy(alpha))
+        dev.sigma.copy_(torch.from_numpy(sigma))
+        self._dev_params_ver = self._host_params_ver
+        self._dev_alpha_ver += 1
+
     def _pull_params(self):
+        """Device alpha / sigma -> the Nodes' host values (one download for all nodes)."""
+        self._params_stale = False
         dev = self._dev
         alpha = dev.alpha.cpu().numpy()
         sigma = dev.sigma.cpu().numpy()
         for k, n in enumerate(self._nodes):
-            n.alpha = alpha[k].copy()
-            n.sigmasqr_inv = float(sigma[k])
+            n._alpha = alpha[k].copy()
+            n._sigmasqr_inv = float(sigma[k])
 
     def _retire_internal_phi(self):
         """Device phi is about to be replaced: internal nodes that still point into it either
@@ -212,6 +250,8 @@ class VarInf(object):
         """Make the device phi matrix hold exactly the current leaves, in DFS order."""
         import torch
         dev = self._ensure_tree()
+        if self._trusted and self._phi_synced:
+            return dev
         leaves = self._leaves
         L = len(leaves)
         src = np.full(L, -1, dtype=np.int32)
@@ -225,6 +265,7 @@ class VarInf(object):
             else:
                 trivial = False
         if trivial:
+            self._phi_synced = True
             return dev
         host_cols = {j: leaf.phi for j, leaf in enumerate(leaves) if src[j] < 0}
         self._retire_internal_phi()
@@ -240,12 +281,16 @@ class VarInf(object):
         for j, leaf in enumerate(leaves):
             leaf._phi_host = None
             leaf._phi_dev = (self._phi_gen, j, 1.0)
+        self._phi_all_dev = self._phi_gen
+        self._phi_synced = True
         return dev
 
     def _sync_gamma(self):
         """Make the device gamma table hold the current nodes' gamma, in pre-order."""
         import torch
         dev = self._ensure_tree()
+        if self._trusted and self._gamma_synced:
+            return dev
         nodes = self._nodes
         K = len(nodes)
         src = np.full(K, -1, dtype=np.int32)
@@ -262,6 +307,7 @@ class VarInf(object):
                 if n._gamma_host is not _DEFAULT and n._gamma_host is not None:
                     host_rows[k] = n._gamma_host
         if trivial:
+            self._gamma_synced = True
             return dev
         if dev.gamma is not None and (src >= 0).any():
             dev.remap_gamma(K, src)
@@ -275,10 +321,12 @@ class VarInf(object):
             if n._gamma_host is not None:
                 n._gamma_host = _DEFAULT
                 n._gamma_dev = (self._gamma_gen, k)
+        self._gamma_synced = True
         return dev
 
     # lazy host views --------------------------------------------------------------------------
     def _note_phi_changed(self):
+        self._phi_synced = False
         self._phi_ver += 1
         self._mass_key = None
         self._estats_key = None
@@ -351,6 +399,15 @@ class VarInf(object):
             self._build_initial_tree()
             self._replicate_initial_alpha()
             self._one_hot_init(Z)
+        self._load_latents(Z)
+        self._ensure_tree()                  # full check once; inside, only flagged changes re-flatten
+        self._trusted += 1
+        try:
+            self._update_body(Z)
+        finally:
+            self._trusted -= 1
+
+    def _update_body(self, Z):
         for _iteration in range(1):
             self.compute_sigma_alpha(Z)
             self.compute_gamma()
@@ -404,13 +461,18 @@ class VarInf(object):
         self._adopt_device_phi()
 
     def _adopt_device_phi(self):
-        self._phi_gen += 1
+        """The device phi matrix was just rewritten by an E-step: every leaf's phi IS its column now."""
         self._phi_ver += 1
         self._phi_cache = {}
         self._mass_key = None
+        if self._trusted and self._phi_synced and self._phi_all_dev == self._phi_gen:
+            return                           # same leaves, same columns: nothing to re-point
+        self._phi_gen += 1
         for j, leaf in enumerate(self._leaves):
             leaf._phi_host = None
             leaf._phi_dev = (self._phi_gen, j, 1.0)
+        self._phi_all_dev = self._phi_gen
+        self._phi_synced = True
 
     # ================================================================== M-step
     def compute_sigma_alpha(self, latent_codes_matrix):         # src/var_inf.py:299-301
@@ -420,7 +482,8 @@ class VarInf(object):
         self._mass_key = (self._phi_gen, self._phi_ver)
         dev.allreduce_stats()
         dev.node_params()
-        self._pull_params()
+        self._params_stale = True            # Node.alpha / .sigmasqr_inv download on first access
+        self._dev_alpha_ver += 1
         self._estats_key = None
 
     # ================================================================== gamma-step
@@ -433,11 +496,14 @@ class VarInf(object):
             dev.leaf_stats(want_q=False, want_mass=True)
             self._mass_key = (self._phi_gen, self._phi_ver)
         dev.gamma_update()
-        self._gamma_gen += 1
         self._gamma_cache = None
-        for k, n in enumerate(self._nodes):
-            n._gamma_host = _DEFAULT
-            n._gamma_dev = (self._gamma_gen, k)
+        if not (self._trusted and self._gamma_synced and self._gamma_all_dev == self._gamma_gen):
+            self._gamma_gen += 1
+            for k, n in enumerate(self._nodes):
+                n._gamma_host = _DEFAULT
+                n._gamma_dev = (self._gamma_gen, k)
+            self._gamma_all_dev = self._gamma_gen
+            self._gamma_synced = True
         if len(self._nodes) == 1:
             self.root._gamma_host = None                        # root-as-leaf (:397-399)
             self.root._gamma_dev = None
@@ -455,7 +521,7 @@ class VarInf(object):
         self._adopt_device_phi()
         self._estats_key = (self._phi_gen, self._phi_ver)
         self._estats_host = None
-        self._estats_alpha = dev.alpha.clone()
+        self._estats_alpha = self._dev_alpha_ver
         return logphi, assign
 
     # ================================================================== split / merge
@@ -464,8 +530,10 @@ class VarInf(object):
         import torch
         dev = self._ensure_tree()
         self._sync_phi()
+        # the statistics of the last E-step are current while phi and the node parameters it used are
+        # (no Node.alpha assigned since, no M-step since: both are tracked, no K x D compare per call)
         fresh = self._estats_key == (self._phi_gen, self._phi_ver) and \
-            self._estats_alpha is not None and self._estats_alpha.shape == dev.alpha.shape and torch.equal(self._estats_alpha, dev.alpha)
+            self._estats_alpha == self._dev_alpha_ver
         if fresh:
             if self._estats_host is None:
                 self._estats_host = dev.estats.cpu().numpy()
@@ -516,6 +584,8 @@ class VarInf(object):
 
         out = rec(node)
         if out:
+            self._struct_dirty = True
+            self._gamma_synced = False
             self._note_phi_changed()
         return out
 
@@ -558,6 +628,8 @@ class VarInf(object):
 
         rec(node)
         if changed[0]:
+            self._struct_dirty = True
+            self._gamma_synced = False
             self._note_phi_changed()
 
     @staticmethod
