@@ -100,6 +100,26 @@ struct LeafOperands {
   float aamax;           // max_l ||alpha_l||^2
 };
 
+// ||z - a||^2 of one (frame, leaf) pair by direct fp32 differences, computed by the 16 lanes of a DPP
+// row together: lane j takes float4 number j, j+16, ... of both rows (coalesced 256 B per row and
+// step), row16_sum adds the partial sums.  All 16 lanes of the row must be active; every lane
+// returns the sum.  Rows are 16-byte aligned and DP floats long (padded).
+template <int DP>
+__device__ __forceinline__ float row16_direct_dist2(const float* __restrict__ zrow, const float* __restrict__ arow,
+                                                    int lane) {
+  float p = 0.f;
+  for (int q = lane & 15; q < DP / 4; q += 16) {
+    const float4 z4 = *reinterpret_cast<const float4*>(zrow + 4 * q);
+    const float4 a4 = *reinterpret_cast<const float4*>(arow + 4 * q);
+    float d;
+    d = z4.x - a4.x; p = fmaf(d, d, p);
+    d = z4.y - a4.y; p = fmaf(d, d, p);
+    d = z4.z - a4.z; p = fmaf(d, d, p);
+    d = z4.w - a4.w; p = fmaf(d, d, p);
+  }
+  return row16_sum(p);
+}
+
 // ------------------------------------------------------------------------------------------
 // One wave tile: 16 frames x NT 16-leaf tiles.  zA/zB hold the lane's raw fp32 fragments.
 // On return acc[T][r] = ||z - alpha||^2 for frame (lane&15), leaf 16T + 4(lane>>4) + r.
@@ -208,40 +228,41 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
       }
     }
   }
-  // rare path, one flagged (frame, leaf) pair at a time: the whole wave computes that pair's
-  // distance by direct fp32 differences (64 lanes split the dims), the owning lane patches it.
+  // rare path: per pass every 16-lane row group (one kg: 16 frames x its leaf quads) takes ONE of its
+  // flagged (frame, leaf) pairs and recomputes it by direct fp32 differences, the group's lanes
+  // splitting the two rows -- four pairs per L2 round trip instead of one whole-wave round trip per
+  // pair.  It matters for tight clusters far from the origin, which flag every frame's own leaf
+  // (profiles/r02_notes.md: 2.3 ms -> 0.93 ms at config 2's shape with ~10 flagged leaves per frame);
+  // a lane-parallel version (one pair per LANE and pass) was 20 % faster there but cost the common
+  // path 8 % through register pressure, this one costs it nothing.
   // (NT > 8: the 32-bit mask aliases tiles T and T+8; every aliased slot is then patched with
   //  its own exact value, which is harmless.)
   while (true) {
     const unsigned long long b = __ballot(pend != 0u);
     if (b == 0ull) break;
-    const int src = __ffsll((long long)b) - 1;
-    const unsigned pm = __builtin_amdgcn_readlane(pend, src);
-    const int idx = __ffs((int)pm) - 1;
-    int64_t ns = row0 + (src & 15);
-    if (ns >= N) ns = N - 1;
+    const unsigned g = (unsigned)(b >> (16 * kg)) & 0xffffu;      // uniform over the row group
+    if (g != 0u) {
+      const int srcj = __ffs((int)g) - 1;                           // owner: frame column of the group
+      const unsigned pm = (unsigned)__shfl((int)pend, 16 * kg + srcj);
+      const int idx = __ffs((int)pm) - 1;
+      int64_t ns = row0 + srcj;
+      if (ns >= N) ns = N - 1;
 #pragma unroll
-    for (int Tb = 0; Tb < NT; Tb += 8) {
-      const int Tq = Tb + (idx >> 2);
-      if (Tq < tiles_valid) {
-        const int leaf = kLT * Tq + 4 * (src >> 4) + (idx & 3);
-        float p = 0.f;
-        for (int d = lane; d < DP; d += 64) {
-          const float df = Z[ns * ldz + d] - lo_.a32[leaf * DP + d];
-          p = fmaf(df, df, p);
-        }
+      for (int Tb = 0; Tb < NT; Tb += 8) {
+        const int Tq = Tb + (idx >> 2);
+        if (Tq < tiles_valid) {
+          const float p = row16_direct_dist2<DP>(Z + ns * ldz, lo_.a32 + (kLT * Tq + 4 * kg + (idx & 3)) * DP, lane);
+          if ((lane & 15) == srcj) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off);
-        if (lane == src) {
+            for (int T = Tb; T < (Tb + 8 < NT ? Tb + 8 : NT); ++T)
 #pragma unroll
-          for (int T = Tb; T < (Tb + 8 < NT ? Tb + 8 : NT); ++T)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (idx == (T - Tb) * 4 + r) acc[T][r] = p;
+              for (int r = 0; r < 4; ++r)
+                if (idx == (T - Tb) * 4 + r) acc[T][r] = p;
+          }
         }
       }
+      if ((lane & 15) == srcj) pend &= pend - 1u;
     }
-    if (lane == src) pend &= ~(1u << idx);
   }
 }
 

@@ -232,29 +232,28 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
             if (d[t][r >> 1][r & 1] < kRefineRel * sn * sn && leaf < L) pend |= 1u << (t * 4 + r);
           }
         }
+        // as in tile_distances: one flagged pair per 16-lane row group (4 frames x 16 leaf columns)
+        // and pass, the group's lanes splitting the rows
         while (true) {
           const unsigned long long b = __ballot(pend != 0u);
           if (b == 0ull) break;
-          const int src = __ffsll((long long)b) - 1;
-          const unsigned pm = __builtin_amdgcn_readlane(pend, src);
-          const int idx = __ffs((int)pm) - 1;
-          int64_t ns = row0 + 4 * (src >> 4) + (idx & 3);
-          if (ns >= N) ns = N - 1;
-          const int leaf = kLT * (ch * kCT + (idx >> 2)) + (src & 15);
-          float p = 0.f;
-          for (int dd = lane; dd < DP; dd += 64) {
-            const float df = Z[ns * ldz + dd] - a32[(int64_t)leaf * DP + dd];
-            p = fmaf(df, df, p);
-          }
+          const unsigned g = (unsigned)(b >> (16 * kg)) & 0xffffu;
+          if (g != 0u) {
+            const int srcc = __ffs((int)g) - 1;                     // owner: leaf column of the group
+            const unsigned pm = (unsigned)__shfl((int)pend, 16 * kg + srcc);
+            const int idx = __ffs((int)pm) - 1;
+            int64_t ns = row0 + 4 * kg + (idx & 3);
+            if (ns >= N) ns = N - 1;
+            const int leaf = kLT * (ch * kCT + (idx >> 2)) + srcc;
+            const float p = row16_direct_dist2<DP>(Z + ns * ldz, a32 + (int64_t)leaf * DP, lane);
+            if (c == srcc) {
 #pragma unroll
-          for (int off = 1; off < 64; off <<= 1) p += __shfl_xor(p, off);
-          if (lane == src) {
+              for (int t = 0; t < kCT; ++t)
 #pragma unroll
-            for (int t = 0; t < kCT; ++t)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (idx == t * 4 + r) d[t][r >> 1][r & 1] = p;
-            pend &= ~(1u << idx);
+                for (int r = 0; r < 4; ++r)
+                  if (idx == t * 4 + r) d[t][r >> 1][r & 1] = p;
+              pend &= pend - 1u;
+            }
           }
         }
       }

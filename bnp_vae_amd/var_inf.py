@@ -80,6 +80,7 @@ class VarInf(object):
         self._trusted = 0            # > 0 inside _update: the flattened tree is re-derived only when flagged
         self._struct_dirty = True
         self._dev_alpha_ver = 0      # bumped whenever the device alpha / sigma change
+        self._mirror = None          # host copy of the (alpha, sigma) last exchanged with the device
         self._phi_synced = False     # device phi holds exactly the current leaves' columns, in order
         self._gamma_synced = False   # same for the device gamma rows
         self._phi_all_dev = -1       # generation at which every leaf was pointed at its device column
@@ -194,6 +195,7 @@ class VarInf(object):
                                 dtype=np.int32)
             is_leaf = np.asarray([1 if n.isLeafNode else 0 for n in nodes], dtype=np.uint8)
             dev.set_tree(parent, is_leaf, alpha, sigma)
+            self._mirror = (alpha, sigma)
             self._sig = sig
             self._nodes = nodes
             self._leaves = [n for n in nodes if n.isLeafNode]
@@ -217,10 +219,14 @@ class VarInf(object):
             self._pull_params()
         alpha = np.asarray([np.asarray(n._alpha, dtype=np.float64) for n in self._nodes])
         sigma = np.asarray([float(n._sigmasqr_inv) for n in self._nodes], dtype=np.float64)
+        self._dev_params_ver = self._host_params_ver
+        m = self._mirror
+        if m is not None and m[0].shape == alpha.shape and np.array_equal(m[0], alpha) and np.array_equal(m[1], sigma):
+            return                               # the device already holds exactly these values
         dev.alpha.copy_(torch.from_numpy(alpha))
         dev.sigma.copy_(torch.from_numpy(sigma))
-        self._dev_params_ver = self._host_params_ver
-        self._dev_alpha_ver += 1
+        self._mirror = (alpha, sigma)
+        self._dev_alpha_ver += 1                 # statistics taken against the old alpha are no longer current
 
     def _pull_params(self):
         """Device alpha / sigma -> the Nodes' host values (one download for all nodes)."""
@@ -228,6 +234,7 @@ class VarInf(object):
         dev = self._dev
         alpha = dev.alpha.cpu().numpy()
         sigma = dev.sigma.cpu().numpy()
+        self._mirror = (alpha, sigma)
         for k, n in enumerate(self._nodes):
             n._alpha = alpha[k].copy()
             n._sigmasqr_inv = float(sigma[k])

@@ -13,7 +13,7 @@ import pytest
 
 from oracle.vi_oracle import (OracleVarInf, snapshot, make_latent_dict, drifting_latents, tree_from_arrays)
 from tests.test_gpu_parity import (load, sub, meta, make_vi, close_params, oracle_from_snapshot, _regular_case,
-                                   PARAM_RTOL, PHI_ATOL)
+                                   PARAM_RTOL, PHI_ATOL, LOGP_ATOL)
 
 pytestmark = pytest.mark.gpu
 
@@ -293,3 +293,44 @@ def test_multi_rank_trajectory_matches_single_rank_golden(golden, world, tmp_pat
                 rows = [i for i in range(0, N, step) if f0 <= i < f1]
                 np.testing.assert_allclose(have['phi'][[i - f0 for i in rows]],
                                            want['phi_rows'][[i // step for i in rows]], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("N,D,bf,levels", [
+    (4000, 64, 8, 2),      # L=64: fused kernel
+    (3000, 64, 8, 3),      # L=512: two-pass row kernel
+    (2500, 32, 5, 2),      # D=32: the row group's lanes 8-15 hold no part of a row
+    (1500, 256, 6, 2),     # D=256: four float4 per lane and row
+    (1800, 128, 4, 3),     # the reference tree's shape
+])
+def test_tight_far_clusters_take_the_exact_distance_path(N, D, bf, levels):
+    """Tight clusters far from the origin: ||z||^2 ~ 64 * 32^2 while a frame is ~4 away from its own leaf, so the
+    fp32 expansion ||z||^2 - 2 z.a + ||a||^2 cannot give that distance to the 2e-5 the log-responsibilities
+    need -- EVERY frame's own leaf (and, in places, neighbouring leaves: several flagged pairs per lane and per
+    16-lane row group) goes through the direct-difference recomputation.  log phi must still match fp64."""
+    ora, vi, _ = _regular_case(N, D, bf, levels, [256], seed=5)
+    oleaves, pleaves = ora.leaves(), vi._dfs_leaves()
+    L = len(oleaves)
+    rng = np.random.RandomState(3)
+    centres = 32.0 * rng.normal(size=(L, D))
+    # a few leaves close together (distance ~ 32 * 2): their neighbours are flagged as well
+    centres[1::7] = centres[0::7][:len(centres[1::7])] + 64.0 * rng.normal(size=(len(centres[1::7]), D)) / np.sqrt(D)
+    Z = (centres[np.arange(N) % L] + 0.5 * rng.normal(size=(N, D))).astype(np.float32)
+    for k, (lo_, lp) in enumerate(zip(oleaves, pleaves)):
+        lo_.alpha = centres[k].copy()
+        lp.alpha = centres[k].copy()
+    ora.compute_phi(Z)
+    logphi, _ = vi.compute_phi(Z, want_logphi=True)
+    got = logphi.cpu().numpy()[:, :L]
+    want = ora.last_log_phi
+    # the own leaf and everything within reach of the tolerance's meaning: entries below -80 are exp-underflow
+    # territory on both sides, compare them only loosely
+    near = want > -80.0
+    np.testing.assert_allclose(got[near], want[near], rtol=0, atol=LOGP_ATOL)
+    np.testing.assert_allclose(got[~near], want[~near], rtol=1e-5, atol=LOGP_ATOL)
+    np.testing.assert_allclose(snapshot(vi)['phi'], snapshot(ora)['phi'], rtol=0, atol=PHI_ATOL)
+    # statistics of the same E-step: S2 = sum phi ||z - alpha||^2 is dominated by the refined distances
+    S0, S2 = vi._leaf_moments()
+    po = snapshot(ora)['phi']
+    d2 = ((Z[:, None, :].astype(np.float64) - centres[None]) ** 2).sum(-1)
+    np.testing.assert_allclose(S0, po.sum(0), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(S2, (po * d2).sum(0), rtol=1e-4, atol=1e-3)

@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--tag", default="")
     ap.add_argument("--only", default="", help="comma-separated phases to run (default: all)")
+    ap.add_argument("--far", type=float, default=0.0,
+                    help="tight far-from-origin clusters: z = FAR*alpha_leaf + 0.5*noise with the tree's alpha scaled "
+                         "alike (every frame's own leaf, and some neighbours, take the E-step's exact-distance path)")
     args = ap.parse_args()
     import torch
     from bench import regular_tree, make_latents
@@ -30,8 +33,13 @@ def main():
     parent, is_leaf = regular_tree(args.bf, args.levels)
     K, L = len(parent), int(is_leaf.sum())
     Z, vid, V = make_latents(torch, dev.device, args.n, args.d, L, 0)
+    alpha = np.random.RandomState(13).normal(size=(K, args.d))
+    if args.far > 0:
+        alpha *= args.far
+        mu = torch.from_numpy(alpha[is_leaf.astype(bool)].astype(np.float32)).to(dev.device)
+        Z = mu[(torch.arange(args.n, device=dev.device) * 7919) % L] + 0.5 * torch.randn_like(Z)
     dev.set_latents(Z, vid, V)
-    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, args.d)), np.ones(K))
+    dev.set_tree(parent, is_leaf, alpha, np.ones(K))
     dev.default_gamma()
     dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
     for _ in range(3):
