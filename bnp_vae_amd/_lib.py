@@ -65,7 +65,8 @@ EXPORTS = {
     "bnpvi_gamma_prior": (_i, [_p, _p, _p, _p, _i, _d, _d, _p, _p, _p]),
     "bnpvi_params_prior": (_i, [_p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p, _i, _d, _p, _p, _p]),
     "bnpvi_estep": (_i, [_p, _p, _p, _i, _p, _i64, _i, _p, _p, _d, _i, _p, _p, _p, _p, _p]),
-    "bnpvi_kmeans_pass": (_i, [_p, _p, _i, _i64, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+    "bnpvi_kmeans_pass_multi": (_i, [_p, _p, _i, _i64, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
+    "bnpvi_kmeans_max_columns": (_i, [_i]),
     "bnpvi_path_distances": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _p]),
     "bnpvi_remap_columns": (_i, [_p, _p, _i, _p, _i, _i64, _i, _p, _p, _p]),
 }

@@ -383,15 +383,26 @@ int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,
                       estats, (hipStream_t)stream);
 }
 
-int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* w,
-                      int ldw, const float* center, int first, float* dist2, int64_t* best_row,
-                      float* best_score, void* stream) {
-  int rc = check_common("bnpvi_kmeans_pass", ctx, N, D, ldz);
+int bnpvi_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* phi,
+                            int ldphi, int L, const int32_t* cols, int J, const float* centres, int first,
+                            float* dist2, int64_t* best_row, double* best_score, void* stream) {
+  int rc = check_common("bnpvi_kmeans_pass_multi", ctx, N, D, ldz);
   if (rc) return rc;
-  BNPVI_REQUIRE(Z && w && dist2 && best_row && best_score, "bnpvi_kmeans_pass: NULL argument");
-  BNPVI_REQUIRE(N >= 1 && ldw >= 1, "bnpvi_kmeans_pass: N=%lld ldw=%d", (long long)N, ldw);
-  return launch_kmeans_pass(ctx, Z, ldz, N, D, w, ldw, center, first, dist2, best_row,
-                            best_score, (hipStream_t)stream);
+  BNPVI_REQUIRE(Z && phi && cols && best_row && best_score, "bnpvi_kmeans_pass_multi: NULL argument");
+  BNPVI_REQUIRE(centres == nullptr || dist2 != nullptr, "bnpvi_kmeans_pass_multi: dist2 is NULL");
+  const int G = bnpvi_padded_dim(D) / 4;
+  BNPVI_REQUIRE(N >= 1 && L >= 0 && ldphi >= 1 && ldphi >= L, "bnpvi_kmeans_pass_multi: N=%lld L=%d ldphi=%d",
+                (long long)N, L, ldphi);
+  BNPVI_REQUIRE(J >= 1 && J <= bnpvi_kmeans_max_columns(D),
+                "bnpvi_kmeans_pass_multi: J=%d columns, at most %d per call at D=%d (%d lanes share a row)", J,
+                bnpvi_kmeans_max_columns(D), D, G);
+  return launch_kmeans_pass_multi(ctx, Z, ldz, N, D, phi, ldphi, L, cols, J, centres, first, dist2, best_row,
+                                  best_score, (hipStream_t)stream);
+}
+
+int bnpvi_kmeans_max_columns(int D) {
+  const int G = bnpvi_padded_dim(D) / 4;
+  return G < 64 ? G : 64;
 }
 
 int bnpvi_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz, int64_t N, int D,

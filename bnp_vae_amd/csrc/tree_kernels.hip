@@ -772,7 +772,7 @@ int launch_prior_table(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* gamma,
 }
 
 // ------------------------------------------------------------------------------------------
-// Weighted farthest-point seeding pass (src/var_inf.py:31-35): G lanes per row, float4 loads.
+// Weighted farthest-point seeding (src/var_inf.py:23-36).
 // ------------------------------------------------------------------------------------------
 struct Best {
   float score;
@@ -783,42 +783,193 @@ __device__ inline bool better(float s, long long r, float bs, long long br) {
   return (s > bs) || (s == bs && r < br);   // np.argmax: first index wins ties
 }
 
-template <int G>   // lanes per row; row width handled = 4*G floats per step
-__global__ __launch_bounds__(256) void kmeans_pass_kernel(const float* __restrict__ Z, int ldz,
-                                                          int64_t N, int Dp,
-                                                          const float* __restrict__ w, int ldw,
-                                                          const float* __restrict__ center, int first,
-                                                          float* __restrict__ dist2,
-                                                          Best* __restrict__ partial) {
+// ------------------------------------------------------------------------------------------
+// Batched seeding: the leaves that split in one split_nodes walk are seeded TOGETHER, one pass over
+// Z per centre index for all of them (J phi columns at a time) instead of one pass per centre per
+// leaf -- Z (the big operand) is read num_centres - 1 times in all, not J * (num_centres - 1) times.
+// ------------------------------------------------------------------------------------------
+struct Best64 {
+  double score;
+  long long row;
+};
+
+__device__ inline bool better64(double s, long long r, double bs, long long br) {
+  return (s > bs) || (s == bs && r < br);
+}
+
+// fp32 phi at or above this is a candidate for the saturated-tie rule below (1 - 1e-5)
+constexpr float kSatCandidate = 0.99999f;
+// the fp32 arg-max counts as saturated from here on (1 - 2e-7: 1.0 or one of its two lower neighbours)
+constexpr float kSaturated = 1.0f - 2e-7f;
+
+// First centres (src/var_inf.py:29-30): arg-max of each of the J phi columns, lowest row on ties.  On
+// well-separated data many frames have phi = 1 - c with c below fp32 resolution -- they all tie at
+// exactly 1.0 in the fp32 matrix, while the reference's fp64 phi = 1 / (1 + c) still orders them
+// (c = the frame's responsibility mass on all OTHER leaves, which fp32 holds to full relative
+// precision).  So next to the fp32 arg-max every column also tracks the arg-max of the fp64
+// 1 / (1 + c) over its candidate frames (fp32 phi >= 1 - 1e-5; c summed in fp64 over the row without the
+// column itself: no cancellation); the final kernel takes the fp64 winner when the fp32 maximum is
+// saturated.  One wave per row, lane j < J owns column cols[j].  L == 0: the columns are plain weights, not
+// rows of responsibilities -- fp32 arg-max only.
+__global__ __launch_bounds__(256) void kmeans_first_multi_kernel(const float* __restrict__ phi, int ldphi,
+                                                                 int64_t N, int L,
+                                                                 const int32_t* __restrict__ cols, int J,
+                                                                 Best* __restrict__ part32,
+                                                                 Best64* __restrict__ part64) {
+  __shared__ Best sh32[4][64];
+  __shared__ Best64 sh64[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mycol = lane < J ? cols[lane] : 0;
+  Best b32;
+  b32.score = -1.f;
+  b32.row = 0x7fffffffffffffffLL;
+  Best64 b64;
+  b64.score = -1.0;
+  b64.row = 0x7fffffffffffffffLL;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+    const float* row = phi + n * ldphi;
+    const float wn = lane < J ? row[mycol] : -1.f;
+    if (lane < J && better(wn, n, b32.score, b32.row)) {
+      b32.score = wn;
+      b32.row = n;
+    }
+    unsigned long long mask = __ballot(L > 0 && lane < J && wn >= kSatCandidate);
+    while (mask != 0ull) {                                     // wave-uniform
+      const int jl = __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      const int col = __builtin_amdgcn_readlane(mycol, jl);
+      double c = 0.0;
+      for (int l = lane; l < L; l += 64)
+        if (l != col) c += (double)row[l];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+      const double s = 1.0 / (1.0 + c);
+      if (lane == jl && better64(s, n, b64.score, b64.row)) {
+        b64.score = s;
+        b64.row = n;
+      }
+    }
+  }
+  sh32[wave][lane] = b32;
+  sh64[wave][lane] = b64;
+  __syncthreads();
+  if (wave == 0 && lane < J) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const Best o = sh32[w][lane];
+      if (better(o.score, o.row, b32.score, b32.row)) b32 = o;
+      const Best64 o64 = sh64[w][lane];
+      if (better64(o64.score, o64.row, b64.score, b64.row)) b64 = o64;
+    }
+    part32[(int64_t)blockIdx.x * J + lane] = b32;
+    part64[(int64_t)blockIdx.x * J + lane] = b64;
+  }
+}
+
+// one workgroup per column j: reduce the partials, apply the saturated-tie rule (part64 != nullptr)
+__global__ __launch_bounds__(256) void kmeans_final_multi_kernel(const Best* __restrict__ part32,
+                                                                 const Best64* __restrict__ part64, int nparts,
+                                                                 int J, int64_t* __restrict__ best_row,
+                                                                 double* __restrict__ best_score) {
+  __shared__ Best sh32[256];
+  __shared__ Best64 sh64[256];
+  const int j = blockIdx.x;
+  Best b32;
+  b32.score = -1.f;
+  b32.row = 0x7fffffffffffffffLL;
+  Best64 b64;
+  b64.score = -1.0;
+  b64.row = 0x7fffffffffffffffLL;
+  for (int b = threadIdx.x; b < nparts; b += blockDim.x) {
+    const Best o = part32[(int64_t)b * J + j];
+    if (better(o.score, o.row, b32.score, b32.row)) b32 = o;
+    if (part64 != nullptr) {
+      const Best64 o64 = part64[(int64_t)b * J + j];
+      if (better64(o64.score, o64.row, b64.score, b64.row)) b64 = o64;
+    }
+  }
+  sh32[threadIdx.x] = b32;
+  sh64[threadIdx.x] = b64;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      const Best o = sh32[threadIdx.x + off];
+      if (better(o.score, o.row, sh32[threadIdx.x].score, sh32[threadIdx.x].row)) sh32[threadIdx.x] = o;
+      const Best64 o64 = sh64[threadIdx.x + off];
+      if (better64(o64.score, o64.row, sh64[threadIdx.x].score, sh64[threadIdx.x].row)) sh64[threadIdx.x] = o64;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const Best w32 = sh32[0];
+    const Best64 w64 = sh64[0];
+    if (part64 != nullptr && w32.score >= kSaturated && w64.score >= 0.0) {
+      best_row[j] = w64.row;
+      best_score[j] = w64.score;
+    } else {
+      // all scores 0 (e.g. all weights 0): normalize() falls back to uniform => index 0
+      best_row[j] = (w32.score > 0.f) ? w32.row : 0;
+      best_score[j] = (double)w32.score;
+    }
+  }
+}
+
+// sum over the G lanes that share a row (G = 8 .. 64, aligned lane groups): DPP inside a 16-lane row,
+// permlane swaps across rows.  Every lane of the group returns the same bits.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+  v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+  if (G >= 16) v += __uint_as_float(__builtin_amdgcn_mov_dpp(__float_as_uint(v), 0x140, 0xf, 0xf, false));  // row_mirror
+  if (G >= 32) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if (G >= 64) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
+
+// Later centres (src/var_inf.py:31-35) for J columns at once.  G = Dp / 4 lanes share a row, one float4 of
+// it each; lane j < J of the group owns column cols[j]: its running min squared distance dist2[n][j],
+// its score w * sqrt(dist2) and its arg-max.  centres: [J][Dp] fp32.
+template <int G>
+__global__ __launch_bounds__(256) void kmeans_pass_multi_kernel(const float* __restrict__ Z, int ldz, int64_t N,
+                                                                const float* __restrict__ phi, int ldphi,
+                                                                const int32_t* __restrict__ cols, int J,
+                                                                const float* __restrict__ centres, int first,
+                                                                float* __restrict__ dist2,
+                                                                Best* __restrict__ partial) {
   __shared__ Best sh[256];
+  constexpr int Dp = 4 * G;
   const int g = threadIdx.x % G;
-  const int64_t rows_per_block = 256 / G;
+  constexpr int64_t rows_per_block = 256 / G;
+  const int mycol = g < J ? cols[g] : 0;
   Best mine;
   mine.score = -1.f;
   mine.row = 0x7fffffffffffffffLL;
   for (int64_t n = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / G; n < N;
        n += (int64_t)gridDim.x * rows_per_block) {
-    float d2 = 0.f;
-    if (center != nullptr) {
-      for (int c = g * 4; c < Dp; c += 4 * G) {
-        const float4 z = *reinterpret_cast<const float4*>(Z + n * ldz + c);
-        const float4 m = *reinterpret_cast<const float4*>(center + c);
-        const float dx = z.x - m.x, dy = z.y - m.y, dz = z.z - m.z, dw = z.w - m.w;
-        d2 += dx * dx + dy * dy + dz * dz + dw * dw;
-      }
-#pragma unroll
-      for (int off = G >> 1; off > 0; off >>= 1) d2 += __shfl_xor(d2, off);
+    const float4 z = *reinterpret_cast<const float4*>(Z + n * ldz + 4 * g);
+    float wn = 0.f, dold = 0.f;
+    if (g < J) {
+      wn = phi[n * ldphi + mycol];
+      if (!first) dold = dist2[n * J + g];
     }
-    if (g == 0) {
-      float score;
-      const float wn = w[n * ldw];
-      if (center == nullptr) {
-        score = wn;
-      } else {
-        const float dm = first ? d2 : fminf(dist2[n], d2);
-        dist2[n] = dm;
-        score = wn * __builtin_amdgcn_sqrtf(dm);
-      }
+    float myd = 0.f;
+    for (int j = 0; j < J; ++j) {
+      const float4 m = *reinterpret_cast<const float4*>(centres + j * Dp + 4 * g);
+      const float dx = z.x - m.x, dy = z.y - m.y, dz = z.z - m.z, dw = z.w - m.w;
+      const float d2 = group_sum<G>(dx * dx + dy * dy + dz * dz + dw * dw);
+      if (g == j) myd = d2;
+    }
+    if (g < J) {
+      const float dm = first ? myd : fminf(dold, myd);
+      dist2[n * J + g] = dm;
+      const float score = wn * __builtin_amdgcn_sqrtf(dm);
       if (better(score, n, mine.score, mine.row)) {
         mine.score = score;
         mine.row = n;
@@ -827,67 +978,58 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(const float* __restric
   }
   sh[threadIdx.x] = mine;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
+  for (int off = 128; off >= G; off >>= 1) {                   // threads off apart own the same column
     if ((int)threadIdx.x < off) {
       const Best o = sh[threadIdx.x + off];
       if (better(o.score, o.row, sh[threadIdx.x].score, sh[threadIdx.x].row)) sh[threadIdx.x] = o;
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+  if ((int)threadIdx.x < J) partial[(int64_t)blockIdx.x * J + threadIdx.x] = sh[threadIdx.x];
 }
 
-__global__ void kmeans_final_kernel(const Best* __restrict__ partial, int n,
-                                    int64_t* __restrict__ best_row, float* __restrict__ best_score) {
-  __shared__ Best sh[256];
-  Best mine;
-  mine.score = -1.f;
-  mine.row = 0x7fffffffffffffffLL;
-  for (int j = threadIdx.x; j < n; j += blockDim.x)
-    if (better(partial[j].score, partial[j].row, mine.score, mine.row)) mine = partial[j];
-  sh[threadIdx.x] = mine;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      const Best o = sh[threadIdx.x + off];
-      if (better(o.score, o.row, sh[threadIdx.x].score, sh[threadIdx.x].row)) sh[threadIdx.x] = o;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    // all scores 0 (e.g. all weights 0): normalize() falls back to uniform => index 0
-    *best_row = (sh[0].score > 0.f) ? sh[0].row : 0;
-    *best_score = sh[0].score;
-  }
-}
-
-int launch_kmeans_pass(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* w,
-                       int ldw, const float* center, int first, float* dist2, int64_t* best_row,
-                       float* best_score, hipStream_t s) {
+int launch_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* phi,
+                             int ldphi, int L, const int32_t* cols, int J, const float* centres, int first,
+                             float* dist2, int64_t* best_row, double* best_score, hipStream_t s) {
   const int Dp = bnpvi_padded_dim(D);
-  const int G = Dp / 4 < 64 ? Dp / 4 : 64;   // 2..64, power of two
+  const int G = Dp / 4;                         // 8 .. 64
+  int64_t blocks;
+  if (centres == nullptr) {
+    blocks = ceil_div(N, (int64_t)4);
+    const int64_t cap = (int64_t)ctx->num_cu * 8;
+    if (blocks > cap) blocks = cap;
+    int rc = ctx->red.ensure((size_t)blocks * J * (sizeof(Best) + sizeof(Best64)));
+    if (rc) return rc;
+    Best64* p64 = (Best64*)ctx->red.ptr;        // 16-byte records first
+    Best* p32 = (Best*)(p64 + blocks * J);
+    hipLaunchKernelGGL(kmeans_first_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, s, phi, ldphi, N, L, cols,
+                       J, p32, p64);
+    BNPVI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kmeans_final_multi_kernel, dim3(J), dim3(256), 0, s, p32, p64, (int)blocks, J, best_row,
+                       best_score);
+    BNPVI_LAUNCH_CHECK();
+    return BNPVI_OK;
+  }
   const int64_t rows_per_block = 256 / G;
-  int64_t blocks = ceil_div(N, rows_per_block);
+  blocks = ceil_div(N, rows_per_block);
   const int64_t cap = (int64_t)ctx->num_cu * 8;
   if (blocks > cap) blocks = cap;
-  int rc = ctx->red.ensure((size_t)blocks * sizeof(Best));
+  int rc = ctx->red.ensure((size_t)blocks * J * sizeof(Best));
   if (rc) return rc;
   Best* part = (Best*)ctx->red.ptr;
-#define KM(GG)                                                                                   \
-  hipLaunchKernelGGL(kmeans_pass_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, Z, ldz, N, \
-                     Dp, w, ldw, center, first, dist2, part)
+#define KMM(GG)                                                                                          \
+  hipLaunchKernelGGL(kmeans_pass_multi_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, Z, ldz, N, phi, \
+                     ldphi, cols, J, centres, first, dist2, part)
   switch (G) {
-    case 2: KM(2); break;
-    case 4: KM(4); break;
-    case 8: KM(8); break;
-    case 16: KM(16); break;
-    case 32: KM(32); break;
-    default: KM(64); break;
+    case 8: KMM(8); break;
+    case 16: KMM(16); break;
+    case 32: KMM(32); break;
+    default: KMM(64); break;
   }
-#undef KM
+#undef KMM
   BNPVI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kmeans_final_kernel, dim3(1), dim3(256), 0, s, part, (int)blocks, best_row,
-                     best_score);
+  hipLaunchKernelGGL(kmeans_final_multi_kernel, dim3(J), dim3(256), 0, s, part, (const Best64*)nullptr,
+                     (int)blocks, J, best_row, best_score);
   BNPVI_LAUNCH_CHECK();
   return BNPVI_OK;
 }

@@ -99,6 +99,29 @@ def select_argmax(score, global_row, group, device):
     return int(grow), owner
 
 
+def select_argmax_many(scores, global_rows, group):
+    """`select_argmax` for J columns at once: scores [J] float64 and global_rows [J] int64 device tensors
+    of this rank's winners.  Returns (winning global rows [J] int64, mask [J] of the columns this rank owns)
+    on the tensors' device -- one all-gather of a [J, 2] table."""
+    import torch
+    if world_size(group) == 1:
+        return global_rows, torch.ones_like(global_rows, dtype=torch.bool)
+    import torch.distributed as dist
+    me = dist.get_rank(group)
+    dev = scores.device
+    mine = torch.stack([scores.to(torch.float64), global_rows.to(torch.float64)], dim=1)
+    if _host_staged(group):
+        mine = mine.cpu()
+    allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allv, mine.contiguous(), group=group)
+    table = torch.stack(allv, dim=0)                                  # [W, J, 2]
+    sc, rows = table[:, :, 0], table[:, :, 1]
+    best = sc.max(dim=0, keepdim=True).values
+    cand = torch.where(sc == best, rows, torch.full_like(rows, float("inf")))
+    grow, owner = cand.min(dim=0)                                     # lowest global row among the best
+    return grow.to(torch.int64).to(dev), (owner == me).to(dev)
+
+
 def broadcast_from(t, owner, group):
     """Broadcast `t` from group rank `owner` (the chosen k-means centre row)."""
     if world_size(group) > 1:

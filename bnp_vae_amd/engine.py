@@ -298,78 +298,70 @@ class DeviceVI(object):
         self.estep(want_stats=want_estats, operands_ready=True)
 
     # ------------------------------------------------------------------ split / merge support
-    def kmeans_seed(self, col, num_centres):
+    def kmeans_seed(self, col, num_centres, responsibilities=True):
         """Weighted farthest-point seeding on phi column `col` (src/var_inf.py:23-36).
+        Returns (chosen rows -- global indices under a process group --, centres (num_centres, D) fp64)."""
+        rows, centres = self.kmeans_seed_multi([col], num_centres, responsibilities)
+        return rows[0], centres[0]
 
-        Returns (chosen rows -- global indices under a process group --, centres (num_centres, D) fp64).
-        Single process: the passes are chained on the device (the arg-max row feeds the next pass's
-        centre through a device gather); the host synchronises twice per call -- after the first
-        centre, whose saturated-tie rule needs the score, and once at the end for the rows."""
-        N = self.N
+    def kmeans_seed_multi(self, cols, num_centres, responsibilities=True):
+        """`kmeans_seed` for several phi columns at once -- the leaves that split in one split_nodes walk
+        (src/var_inf.py:221-224 seeds them one after the other; the seedings are independent).  One pass over
+        Z per centre index for all of them; the arg-max rows feed the next pass's centres through a device
+        gather, the host waits once at the end (single process) or exchanges one small table per pass.
+
+        First centres = arg-max of the column.  On well-separated data many frames have phi = 1 - c with c
+        below fp32 resolution: in the fp32 matrix they all tie at exactly 1.0, while the reference's fp64
+        phi = 1 / (1 + c) still orders them; the kernel resolves a saturated maximum that way
+        (`responsibilities=False`: the columns are plain weights, not rows of a softmax -- fp32 arg-max only).
+
+        Returns (rows [J][num_centres] -- global indices under a process group --, centres
+        [J][num_centres][D] fp64)."""
+        J = len(cols)
+        D, Dp, N = self.D, self.Dp, self.N
+        jmax = int(lib.bnpvi_kmeans_max_columns(D))
+        if J > jmax:
+            rows, cen = [], []
+            for lo in range(0, J, jmax):
+                r, c = self.kmeans_seed_multi(cols[lo:lo + jmax], num_centres, responsibilities)
+                rows.extend(r)
+                cen.extend(c)
+            return rows, np.asarray(cen)
         multi = vdist.world_size(self.group) > 1
-        dist2 = self._empty((max(N, 1),), torch.float32)
-        best_row = torch.zeros((1,), dtype=torch.int64, device=self.device)
-        best_score = torch.zeros((1,), dtype=torch.float32, device=self.device)
-        centre = torch.zeros((self.Dp,), dtype=torch.float32, device=self.device)
-        wptr = C.c_void_p(self.phi.data_ptr() + 4 * col)
-        rows, row_t, centres = [], [], []
+        cols_t = torch.as_tensor(np.asarray(cols, dtype=np.int32), device=self.device)
+        best_row = torch.zeros((J,), dtype=torch.int64, device=self.device)
+        best_score = torch.full((J,), -1.0, dtype=torch.float64, device=self.device)
+        dist2 = self._empty((max(N, 1), J), torch.float32) if num_centres > 1 else None
+        centres = torch.zeros((J, Dp), dtype=torch.float32, device=self.device)
+        picked = []                                                  # per pass: [J, Dp] fp32 rows of Z
+        rows = []                                                    # per pass: [J] (global) row indices
         for k in range(num_centres):
             if N > 0:
-                check(lib.bnpvi_kmeans_pass(self.ctx, _ptr(self.Z), self.Dp, N, self.D, wptr,
-                                            int(self.phi.shape[1]), _ptr(centre if k > 0 else None),
-                                            1 if k <= 1 else 0, _ptr(dist2), _ptr(best_row),
-                                            _ptr(best_score), self._stream()), "bnpvi_kmeans_pass")
-            if multi:
-                if N > 0:
-                    row, score = int(best_row.item()), float(best_score.item())
-                    if k == 0:
-                        row, score = self._first_centre_among_saturated(col, row, score)
-                else:
-                    row, score = 0, -1.0
-                # arg-max over ranks: (score, global row), lowest row wins ties (np.argmax).  With
-                # all-zero scores every rank reports its local row 0, so global row 0 wins (the
-                # uniform fallback of normalize()); empty ranks (score -1) lose.
-                grow, owner = vdist.select_argmax(score, self.row_offset + row, self.group, self.device)
-                if owner == torch.distributed.get_rank(self.group):
-                    centre.copy_(self.Z[grow - self.row_offset])
-                vdist.broadcast_from(centre, owner, self.group)
+                check(lib.bnpvi_kmeans_pass_multi(self.ctx, _ptr(self.Z), Dp, N, D, _ptr(self.phi),
+                                                  int(self.phi.shape[1]), int(self.tree.L) if responsibilities else 0,
+                                                  _ptr(cols_t), J,
+                                                  _ptr(centres if k > 0 else None), 1 if k <= 1 else 0,
+                                                  _ptr(dist2), _ptr(best_row), _ptr(best_score), self._stream()),
+                      "bnpvi_kmeans_pass_multi")
+            if not multi:
+                centres = self.Z.index_select(0, best_row)          # device gather: no host round trip
+                rows.append(best_row.clone())
+            else:
+                # arg-max over ranks per column: (score, global row), lowest row wins ties (np.argmax).  With
+                # all-zero scores every rank reports its local row 0, so global row 0 wins (the uniform
+                # fallback of normalize()); empty ranks (score -1) lose.  The owners' rows travel in one
+                # all-reduce of a [J, Dp] table that is zero everywhere else.
+                grow, mine = vdist.select_argmax_many(best_score, best_row + self.row_offset, self.group)
+                centres = torch.zeros((J, Dp), dtype=torch.float32, device=self.device)
+                if N > 0 and bool(mine.any()):
+                    idx = torch.nonzero(mine).flatten()
+                    centres[idx] = self.Z.index_select(0, grow[idx] - self.row_offset)
+                vdist.allreduce_sum_(centres, self.group)
                 rows.append(grow)
-                centres.append(centre[:self.D].to(torch.float64).cpu().numpy())
-                continue
-            if k == 0:
-                row, score = int(best_row.item()), float(best_score.item())
-                row2, _ = self._first_centre_among_saturated(col, row, score)
-                if row2 != row:
-                    best_row.fill_(row2)
-            centre.copy_(self.Z.index_select(0, best_row)[0])           # device gather: no host round trip
-            row_t.append(best_row.clone())
-        if not multi:
-            rt = torch.cat(row_t)
-            rows = [int(r) for r in rt.cpu().numpy()]
-            return rows, self.Z.index_select(0, rt)[:, :self.D].to(torch.float64).cpu().numpy()
-        return rows, np.asarray(centres)
-
-    def _first_centre_among_saturated(self, col, row, score):
-        """First k-means centre = arg-max of the leaf's responsibilities (src/var_inf.py:29-30).  On
-        well-separated data many frames have phi = 1 - c with c below fp32 resolution: in the fp32
-        matrix they all tie at exactly 1.0, while the reference's fp64 phi = 1 / (1 + c) still
-        orders them (c = the frame's responsibility mass on all OTHER leaves, which fp32 holds to
-        full relative precision).  When the fp32 maximum is saturated the winner is re-picked the
-        reference's way: largest fp64 1 / (1 + c), first index among equals.  c comes from two strided
-        fp64 row sums over the other columns (no gather of the tied rows, no cancellation).
-        Returns (row, fp64 score)."""
-        if score < 1.0 - 2e-7:
-            return row, score
-        L = self.tree.L
-        c = torch.zeros((self.N,), dtype=torch.float64, device=self.device)
-        if col > 0:
-            c += self.phi[:, :col].sum(dim=1, dtype=torch.float64)
-        if col + 1 < L:
-            c += self.phi[:, col + 1:L].sum(dim=1, dtype=torch.float64)
-        phi64 = 1.0 / (1.0 + c)
-        best = phi64.max()
-        first = torch.nonzero(phi64 == best).flatten()[0]
-        return int(first), float(best)
+            picked.append(centres)
+        rows_h = torch.stack(rows, dim=1).cpu().numpy()              # [J, num_centres]; the one wait
+        cen_h = torch.stack(picked, dim=1)[:, :, :D].to(torch.float64).cpu().numpy()
+        return [[int(r) for r in rr] for rr in rows_h], cen_h
 
     def remap_phi(self, new_L, src, scale):
         """phi_new[:, j] = scale[j] * phi_old[:, src[j]] (split / merge column surgery)."""

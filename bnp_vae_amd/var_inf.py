@@ -205,8 +205,10 @@ class VarInf(object):
                 n._owner = self
             self._dev_params_ver = self._host_params_ver
             self._dev_alpha_ver += 1
-        else:
-            # public methods called directly: a caller may also have edited a Node's alpha IN PLACE
+        elif not self._params_stale:
+            # public methods called directly: a caller may also have edited a Node's alpha IN PLACE.  (While
+            # the device values are newer than the Nodes' -- nobody has read a Node.alpha since the last
+            # M-step, the getter would have downloaded them -- there is nothing a caller could have edited.)
             self._push_params()
         self._struct_dirty = False
         return dev
@@ -246,7 +248,8 @@ class VarInf(object):
         or fall back to the Node default."""
         keep = self.retain_internal_phi == 'always' or \
             (self.retain_internal_phi == 'auto' and self.num_splits == 1)
-        for n in self._preorder():
+        flat = self._trusted and not self._struct_dirty and self._sig is not None
+        for n in (self._nodes if flat else self._preorder()):
             if not n.isLeafNode and n._phi_dev is not None:
                 if keep and n._phi_host is None:
                     got = self._fetch_phi(n)
@@ -414,11 +417,32 @@ class VarInf(object):
         finally:
             self._trusted -= 1
 
+    def _vi_iteration(self, Z):
+        """compute_sigma_alpha + compute_gamma + compute_phi of one call, launched the way
+        DeviceVI.iteration (the benchmarked step) launches them: one statistics pass, its all-reduce, ONE
+        mid-step launch (node parameters, gamma-step, prior table, leaf operands) and the E-step with its
+        split / merge statistics -- same results as the three public methods
+        (tests/test_gpu_parity.py::test_fused_iteration_matches_separate_calls)."""
+        dev = self._load_latents(Z)
+        self._sync_phi()
+        dev.leaf_stats(want_q=False, want_mass=True)
+        dev.allreduce_stats()
+        dev.params_prior()                   # consumes (and re-zeroes) the per-video masses
+        self._mass_key = None
+        self._params_stale = True            # Node.alpha / .sigmasqr_inv download on first access
+        self._dev_alpha_ver += 1
+        self._gamma_now_on_device()
+        self._retire_internal_phi()
+        dev.estep(want_stats=True, operands_ready=True)
+        dev.allreduce_estats()
+        self._adopt_device_phi()
+        self._estats_key = (self._phi_gen, self._phi_ver)
+        self._estats_host = None
+        self._estats_alpha = self._dev_alpha_ver
+
     def _update_body(self, Z):
         for _iteration in range(1):
-            self.compute_sigma_alpha(Z)
-            self.compute_gamma()
-            self.compute_phi(Z)
+            self._vi_iteration(Z)
             self.print_phi(self.root)
         split = self.split_nodes(self.root, Z, self.STDEV_THR + 100.0 * np.exp(-1.0 * self.decay_coeff))
         if split:
@@ -503,6 +527,10 @@ class VarInf(object):
             dev.leaf_stats(want_q=False, want_mass=True)
             self._mass_key = (self._phi_gen, self._phi_ver)
         dev.gamma_update()
+        self._gamma_now_on_device()
+
+    def _gamma_now_on_device(self):
+        """The device gamma table was just rewritten by a gamma-step: every node's gamma IS its row now."""
         self._gamma_cache = None
         if not (self._trusted and self._gamma_synced and self._gamma_all_dev == self._gamma_gen):
             self._gamma_gen += 1
@@ -563,6 +591,8 @@ class VarInf(object):
         col = {id(l): j for j, l in enumerate(self._leaves)}
         N = float(self._num_frames_global())
 
+        todo = []                                # (leaf, phi column) of the leaves that split, in walk order
+
         def rec(n):
             self._log('split_nodes', n.node_id)
             if n.isLeafNode:
@@ -572,16 +602,7 @@ class VarInf(object):
                 stdev = np.sqrt(np.sqrt(S2[j]) / S0[j])
                 self._log(n.node_id, stdev, split_thr)
                 if stdev > split_thr:
-                    best_K = self.num_splits
-                    n.isLeafNode = False
-                    _rows, centres = dev.kmeans_seed(j, best_K)
-                    for k in range(best_K):
-                        child = self._new_node(n.node_id + '-' + str(k), n)
-                        child.alpha = centres[k, :].copy()
-                        child.sigmasqr_inv = n.sigmasqr_inv
-                        gen, c, sc = n._phi_dev
-                        child._phi_dev = (gen, c, sc / best_K)       # phi_parent / best_K
-                        n.children.append(child)
+                    todo.append((n, j))
                     return True
                 return None
             result = False
@@ -590,6 +611,22 @@ class VarInf(object):
             return result
 
         out = rec(node)
+        if todo:
+            # the reference seeds each splitting leaf as the walk reaches it (:221-224); the seedings are
+            # independent of each other and of the walk, so they run batched (one pass over Z per centre
+            # index for all leaves) and the children are created afterwards, in the walk's order -- which
+            # also keeps the order of Node.__init__'s np.random draws
+            best_K = self.num_splits
+            _rows, centres = dev.kmeans_seed_multi([j for _n, j in todo], best_K)
+            for (n, _j), cen in zip(todo, centres):
+                n.isLeafNode = False
+                for k in range(best_K):
+                    child = self._new_node(n.node_id + '-' + str(k), n)
+                    child.alpha = cen[k, :].copy()
+                    child.sigmasqr_inv = n.sigmasqr_inv
+                    gen, c, sc = n._phi_dev
+                    child._phi_dev = (gen, c, sc / best_K)       # phi_parent / best_K
+                    n.children.append(child)
         if out:
             self._struct_dirty = True
             self._gamma_synced = False
@@ -651,7 +688,7 @@ class VarInf(object):
             dev.set_latents(data.astype(np.float32), np.zeros(N, dtype=np.int32), 1)
             dev.phi = torch.zeros((N, 32), dtype=torch.float32, device=dev.device)
             dev.phi[:, 0].copy_(torch.from_numpy(np.asarray(weights, dtype=np.float32)))
-            _rows, centres = dev.kmeans_seed(0, K)
+            _rows, centres = dev.kmeans_seed(0, K, responsibilities=False)
         finally:
             dev.close()
         return centres

@@ -172,18 +172,30 @@ int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int 
                 const float* prior_dev, double sigma_z_sqrinv, int mode, float* phi_dev,
                 float* logphi_dev, int32_t* assign_dev, double* estats_dev, void* stream);
 
-/* ---- weighted farthest-point seeding pass: src/var_inf.py:23-36 -------------------------
- * One pass per new centre.  dist2_dev[N] holds the running min squared distance to the
- * centres chosen so far (ignored and overwritten when first != 0: the reference starts
- * from a uniform 1/N).  Computes score[n] = w[n]*sqrt(min(dist2[n], ||z_n-c||^2)) for the
- * centre `center_dev` (float [padded D] on the device, e.g. Z_dev + row*ldz; NULL for the
- * initial arg-max of w alone),
- * updates dist2, and writes the arg-max row (lowest index on ties) to *best_row_dev and its
- * score to *best_score_dev.  w = phi column: w_dev + n*ldw. */
-int bnpvi_kmeans_pass(bnpvi_ctx* ctx, const float* Z_dev, int ldz, int64_t N, int D,
-                      const float* w_dev, int ldw, const float* center_dev, int first,
-                      float* dist2_dev, int64_t* best_row_dev, float* best_score_dev,
-                      void* stream);
+/* ---- weighted farthest-point seeding: src/var_inf.py:23-36, 221-224 ------------------------
+ * weighted_kmeans picks num_splits centres among the frames: the first is the arg-max of the weights
+ * (a leaf's phi column, :29-30), each later one the arg-max of w[n] * min_c ||z_n - c|| over the
+ * centres c chosen so far (:31-35; the reference starts the running minimum from a uniform 1/N, i.e.
+ * the first distance replaces it).  One call = one pass = one new centre, for J phi columns at once:
+ * split_nodes seeds every splitting leaf (:224), one leaf after the other; the seedings are independent,
+ * so the leaves of one walk share the passes over Z.  cols_dev[J] = the leaves' phi columns (int32,
+ * device); J <= bnpvi_kmeans_max_columns(D) (the padded D / 4 lanes that share a row each own a column).
+ *   centres_dev == NULL : first centres = arg-max of each column (phi_dev [N][ldphi]), lowest row on
+ *                         ties (np.argmax).  With L > 0 the columns are rows of responsibilities over L
+ *                         leaves and a saturated fp32 maximum (>= 1 - 2e-7: many frames tie at 1.0 where
+ *                         the reference's fp64 phi still orders them) is resolved the fp64 way, by the
+ *                         largest 1 / (1 + c), c = the row's mass on the other L - 1 columns; L = 0:
+ *                         plain weights, fp32 arg-max only.  dist2_dev is not touched.
+ *   centres_dev != NULL : float [J][padded D], column j's newest centre (e.g. gathered rows of Z).
+ *                         dist2_dev [N][J] is the running min squared distance (overwritten when
+ *                         first != 0); score = w * sqrt(dist2).
+ * best_row_dev[J] (int64) and best_score_dev[J] (double) receive each column's arg-max; all-zero
+ * scores give row 0 (normalize()'s uniform fallback, :418-425). */
+int bnpvi_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z_dev, int ldz, int64_t N, int D,
+                            const float* phi_dev, int ldphi, int L, const int32_t* cols_dev, int J,
+                            const float* centres_dev, int first, float* dist2_dev,
+                            int64_t* best_row_dev, double* best_score_dev, void* stream);
+int bnpvi_kmeans_max_columns(int D);
 
 /* ---- distances of every frame to the nodes on the path of its leaf ---------------------------
  * The per-node ranking of src/create_hierarchy.py:40-53 ("top-K closest frames" of a node among

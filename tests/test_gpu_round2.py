@@ -334,3 +334,50 @@ def test_tight_far_clusters_take_the_exact_distance_path(N, D, bf, levels):
     d2 = ((Z[:, None, :].astype(np.float64) - centres[None]) ** 2).sum(-1)
     np.testing.assert_allclose(S0, po.sum(0), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(S2, (po * d2).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,D,L,K,sharp", [
+    (3000, 32, 20, 3, 1.0),       # D=32: 8 lanes share a row -> 20 columns go in three batches
+    (2500, 64, 40, 4, 1.0),       # 16 lanes per row, three batches
+    (2000, 128, 33, 4, 1.0),      # 32 lanes per row (crosses a DPP row), two batches
+    (1500, 200, 70, 2, 1.0),      # D=200 -> 256: one wave per row, two batches
+    (4000, 64, 12, 4, 40.0),      # saturated: most frames have fp32 phi == 1.0 on their leaf
+    (4000, 128, 9, 3, 25.0),
+    (777, 48, 5, 6, 3.0),         # ragged N, D=48 -> 64, more centres than columns
+])
+def test_batched_kmeans_seeding_against_oracle(N, D, L, K, sharp):
+    """`DeviceVI.kmeans_seed_multi` (all splitting leaves of one split_nodes walk seeded together, one pass
+    over Z per centre index) against the oracle's weighted_kmeans (src/var_inf.py:23-36) run column by column
+    on the fp64 responsibilities the fp32 device matrix was rounded from.  `sharp` scales the logits: at
+    25-40 most frames sit at phi = 1.0 in fp32 and the first centre is decided by the fp64 tie rule."""
+    import torch
+    from bnp_vae_amd.engine import DeviceVI
+    rng = np.random.RandomState(N + D)
+    Z = rng.normal(size=(N, D)).astype(np.float32)
+    logits = sharp * rng.normal(size=(N, L))
+    phi64 = np.exp(logits - logits.max(1, keepdims=True))
+    phi64 /= phi64.sum(1, keepdims=True)
+    dev = DeviceVI(device=0)
+    try:
+        parent = np.asarray([-1] + [0] * L, dtype=np.int32)
+        is_leaf = np.asarray([0] + [1] * L, dtype=np.uint8)
+        dev.set_latents(Z, np.zeros(N, dtype=np.int32), 1)
+        dev.set_tree(parent, is_leaf, np.zeros((L + 1, D)), np.ones(L + 1))
+        dev.alloc_phi()
+        dev.phi.zero_()
+        dev.phi[:, :L].copy_(torch.from_numpy(phi64.astype(np.float32)))
+        if sharp >= 25.0:
+            sat = (dev.phi[:, :L] >= 1.0 - 2e-7).sum(0).cpu().numpy()
+            assert (sat >= 2).sum() >= L // 2, "the case is meant to have tied fp32 maxima"
+        cols = list(range(L))
+        rows, centres = dev.kmeans_seed_multi(cols, K)
+        single_rows, single_centres = dev.kmeans_seed(L // 2, K)
+    finally:
+        dev.close()
+    assert np.asarray(centres).shape == (L, K, D)
+    for j in cols:
+        want = OracleVarInf.weighted_kmeans(Z.astype(np.float64), phi64[:, j], K)
+        np.testing.assert_array_equal(centres[j], want, err_msg="column %d" % j)
+        np.testing.assert_array_equal(Z[rows[j]].astype(np.float64), want)
+    assert single_rows == rows[L // 2]
+    np.testing.assert_array_equal(single_centres, centres[L // 2])
