@@ -225,13 +225,14 @@ class Runner(object):
         kern_bytes = N * 4.0 * (D + L)            # per launch: E reads Z + writes phi; M reads Z + phi
         dom, dom_ms = ("estep", e_ms) if e_ms >= m_ms else ("mstep_stats", m_ms)
         achieved = kern_bytes / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_at = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.isfile(pmc):
             try:
                 rec = json.load(open(pmc)).get("%s:%s" % (cfg, dom))
-                if rec and rec.get("N") == N:
-                    traffic = rec["hbm_bytes_per_launch"]
+                if rec:      # counters of a streaming kernel: linear in the frame count
+                    traffic = rec["hbm_bytes_per_launch"] * (N / float(rec["N"]))
+                    traffic_at = rec["N"]
             except Exception:
                 traffic = None
         return {
@@ -240,6 +241,7 @@ class Runner(object):
             "allreduce_bytes_per_step": (L * (1 + D) * 8 + (L * 2 * 8 if want_estats else 0)) if self.world > 1 else 0,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_measured_at_N": traffic_at,
                          "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_ms": dom_ms,
                          "estep_ms": e_ms, "mstep_stats_ms": m_ms,
                          "iteration_frac": N * 8.0 * (D + L) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
