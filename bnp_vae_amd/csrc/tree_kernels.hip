@@ -341,26 +341,30 @@ __device__ __forceinline__ void wave_inclusive_scan(double* a, int n, int lane) 
   wave_sync_lds();
 }
 
-// One video by one wave.  leaf_sigma == nullptr: the leaf precisions come straight from the
-// statistics (sigma_l = sB + sZ*S0_l, src/var_inf.py:268-272) -- used when the node-parameter
+// One video by one wave.  leaf_sigma == nullptr: the leaf precisions come straight from
+// the statistics (sigma_l = sB + sZ*S0_l, src/var_inf.py:268-272) -- used when the node-parameter
 // update runs concurrently in the same launch.  ZERO_MASS: the mass row is zeroed once read.
+// LDS per wave: Pm[L] (leaf-mass prefix, later the leaves' un-normalised log priors), e0[K], P[K].
+// (A team of four waves per video was tried for K = 585 -- the chain is fp64 throughput, not latency:
+// 158 us against 130 us for one wave per video, profiles/r02_notes.md.)
 template <bool DO_GAMMA, bool DO_PRIOR, bool ZERO_MASS>
 __device__ __forceinline__ void stick_wave_video(
-    int v, int lane, double* Pm, double* e0, double* P, double* mass_rw, const double* __restrict__ mass,
-    double* gamma, const double* __restrict__ leaf_sigma, const double* __restrict__ stats, int W, double sB,
-    double sZ, const int32_t* __restrict__ parent, const int32_t* __restrict__ node_of_leaf,
-    const int32_t* __restrict__ leaf_lo, const int32_t* __restrict__ leaf_hi, int K, int L, int Lp,
-    double gamma_hyper, double half_sz, float* __restrict__ prior, double* __restrict__ on_out,
-    double* __restrict__ before_out) {
+    int v, int tid, double* Pm, double* e0, double* P, double* mass_rw,
+    const double* __restrict__ mass, double* gamma, const double* __restrict__ leaf_sigma,
+    const double* __restrict__ stats, int W, double sB, double sZ, const int32_t* __restrict__ parent,
+    const int32_t* __restrict__ node_of_leaf, const int32_t* __restrict__ leaf_lo,
+    const int32_t* __restrict__ leaf_hi, int K, int L, int Lp, double gamma_hyper, double half_sz,
+    float* __restrict__ prior, double* __restrict__ on_out, double* __restrict__ before_out) {
+  constexpr int T = 64;
   if (DO_GAMMA) {
-    for (int l = lane; l < L; l += 64) {
+    for (int l = tid; l < L; l += T) {
       Pm[l] = mass[(int64_t)v * L + l];
       if (ZERO_MASS) mass_rw[(int64_t)v * L + l] = 0.0;
     }
     wave_sync_lds();
-    wave_inclusive_scan(Pm, L, lane);
+    wave_inclusive_scan(Pm, L, tid);
   }
-  for (int k = lane; k < K; k += 64) {
+  for (int k = tid; k < K; k += T) {
     double2 g;
     if (DO_GAMMA) {
       const int lo = leaf_lo[k], hi = leaf_hi[k];
@@ -384,47 +388,44 @@ __device__ __forceinline__ void stick_wave_video(
     }
   }
   if (!DO_PRIOR) return;
-  wave_sync_lds();
-  wave_inclusive_scan(P, K, lane);
+  wave_sync_lds();                       // also: every read of the mass prefix Pm is done
+  wave_inclusive_scan(P, K, tid);
 
-  double best = -INFINITY;
 #ifdef BNPVI_TABLATE_NOPRIORPASS
-  for (int l = lane; l < Lp; l += 64) prior[(int64_t)v * Lp + l] = l < L ? (float)P[node_of_leaf[l] > 0 ? 1 : 0] : -INFINITY;
+  for (int l = tid; l < Lp; l += T)
+    prior[(int64_t)v * Lp + l] = l < L ? (float)P[node_of_leaf[l] > 0 ? 1 : 0] : -INFINITY;
   return;
 #endif
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int l = lane; l < Lp; l += 64) {
-      if (l >= L) {
-        if (pass == 1) prior[(int64_t)v * Lp + l] = -INFINITY;
-        continue;
-      }
-      const int k = node_of_leaf[l];
-      double on = 0.0, anc = 0.0;
-      if (k > 0) {
-        on = e0[k];
-        int a = parent[k];
-        while (a > 0) {
-          on += e0[a];
-          anc += P[a] - P[a - 1];
-          a = parent[a];
-        }
-      }
-      const double before = (k > 0 ? P[k - 1] : 0.0) - anc;
-      const double sig = leaf_sigma ? leaf_sigma[k] : sB + sZ * stats[(int64_t)l * W];
-      const double val = on + before - half_sz / sig;
-      if (pass == 0) {
-        best = fmax(best, val);
-      } else {
-        prior[(int64_t)v * Lp + l] = (float)((val - best) * 1.4426950408889634);   // log2 units
-        if (on_out) on_out[(int64_t)v * L + l] = on;
-        if (before_out) before_out[(int64_t)v * L + l] = before;
+  // pass 0: un-normalised log prior of every leaf (kept in Pm) and its maximum; pass 1: the table
+  double best = -INFINITY;
+  for (int l = tid; l < L; l += T) {
+    const int k = node_of_leaf[l];
+    double on = 0.0, anc = 0.0;
+    if (k > 0) {
+      on = e0[k];
+      int a = parent[k];
+      while (a > 0) {
+        on += e0[a];
+        anc += P[a] - P[a - 1];
+        a = parent[a];
       }
     }
-    if (pass == 0) {
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
-    }
+    const double before = (k > 0 ? P[k - 1] : 0.0) - anc;
+    const double sig = leaf_sigma ? leaf_sigma[k] : sB + sZ * stats[(int64_t)l * W];
+    const double val = on + before - half_sz / sig;
+    best = fmax(best, val);
+    Pm[l] = val;                         // read back by the same thread only
+    if (on_out) on_out[(int64_t)v * L + l] = on;
+    if (before_out) before_out[(int64_t)v * L + l] = before;
   }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) best = fmax(best, __shfl_xor(best, off));
+  for (int l = tid; l < Lp; l += T)
+    prior[(int64_t)v * Lp + l] = l < L ? (float)((Pm[l] - best) * 1.4426950408889634) : -INFINITY;   // log2 units
+}
+
+__host__ __device__ inline size_t stick_wave_lds(int K, int L) {
+  return (size_t)(L + 2 * K) * sizeof(double);
 }
 
 template <bool DO_GAMMA, bool DO_PRIOR>
@@ -689,7 +690,7 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
                         double gamma_hyper, double* gamma, float* prior, hipStream_t s) {
   const int DP = bnpvi_padded_dim(D);
   // stick workgroups: as many of the 16 waves take a video as fit 64 KB of LDS (L + 2K doubles each)
-  const size_t per_wave = (size_t)(t->L + 2 * t->K) * sizeof(double);
+  const size_t per_wave = stick_wave_lds(t->K, t->L);
   int stick_waves = (int)((size_t)64 * 1024 / per_wave);
   stick_waves = stick_waves > kMidWaves ? kMidWaves : stick_waves;
   size_t lds = (size_t)stick_waves * per_wave;
@@ -733,7 +734,7 @@ template <bool DO_GAMMA, bool DO_PRIOR>
 static int launch_stick_wave(const bnpvi_tree* t, const double* mass, double* gamma, const double* sigma,
                              int V, double gamma_hyper, double sZ, float* prior, double* on, double* before,
                              hipStream_t s) {
-  const size_t lds = (size_t)kStickWaves * (t->L + 2 * t->K) * sizeof(double);
+  const size_t lds = (size_t)kStickWaves * stick_wave_lds(t->K, t->L);
   auto k = stick_wave_kernel<DO_GAMMA, DO_PRIOR>;
   if (lds > 48 * 1024)
     BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
