@@ -297,7 +297,9 @@ int bnpvi_tree_leaf_nodes(const bnpvi_tree* t, int32_t* out_host) {
 
 static int check_common(const char* fn, bnpvi_ctx* ctx, int64_t N, int D, int ldz) {
   BNPVI_REQUIRE(ctx != nullptr, "%s: ctx is NULL", fn);
-  BNPVI_REQUIRE(N >= 0 && N < (int64_t(1) << 40), "%s: N=%lld", fn, (long long)N);
+  // 2^33 frames: every per-frame grid (N/4 workgroups at the smallest) stays below 2^31; 288 GB of HBM
+  // hold < 2^31 frames of the smallest Z + phi anyway
+  BNPVI_REQUIRE(N >= 0 && N < (int64_t(1) << 33), "%s: N=%lld (at most 2^33 - 1 frames)", fn, (long long)N);
   int Dp = bnpvi_padded_dim(D);
   BNPVI_REQUIRE(D >= 1 && Dp > 0, "%s: D=%d unsupported (1..256)", fn, D);
   BNPVI_REQUIRE(ldz >= Dp && ldz % 4 == 0,

@@ -97,7 +97,11 @@ struct bnpvi_ctx {
   const double* ops_alpha = nullptr;
   int ops_D = 0;
   // per-video mass buffer that bnpvi_params_prior left zeroed (bnpvi_leaf_stats skips its memset)
+  // the per-video mass buffer the last bnpvi_params_prior left zeroed (pointer, element count, stream): the
+  // next bnpvi_leaf_stats on exactly that buffer, size and stream skips its memset
   const double* mass_clean = nullptr;
+  size_t mass_clean_elems = 0;
+  hipStream_t mass_clean_stream = nullptr;
   // this device's address of the static no-allocation scratch array (noalloc.hip), resolved once in
   // bnpvi_ctx_create; while slab_override is set the statistics kernels put their partial-sum
   // slabs there instead of in `slabs` (bnpvi_leaf_stats_noalloc)

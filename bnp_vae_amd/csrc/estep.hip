@@ -231,9 +231,9 @@ __global__ __launch_bounds__(256) void estep_normalize_cols_kernel(
   __shared__ float comb[4][256][8];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int c4 = blockIdx.x * 256 + lane * 4;            // this lane's 4 leaves
+  const int c4 = blockIdx.y * 256 + lane * 4;            // this lane's 4 leaves
   const bool col_ok = c4 < Lp;                           // Lp is a multiple of 4
-  const int64_t r0 = (int64_t)blockIdx.y * kNormRows;
+  const int64_t r0 = (int64_t)blockIdx.x * kNormRows;
   const int64_t r1 = r0 + kNormRows < N ? r0 + kNormRows : N;
   float s0[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (col_ok) {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void estep_normalize_cols_kernel(
     __syncthreads();
     // thread t of the workgroup owns leaf (window, t): lane t/4, component t%4
     const int t = threadIdx.x;
-    const int leaf = blockIdx.x * 256 + t;
+    const int leaf = blockIdx.y * 256 + t;
     if (leaf < L) {
       double a = 0.0, b = 0.0;
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void estep_normalize_cols_kernel(
         a += (double)comb[w][t >> 2][t & 3];
         b += (double)comb[w][t >> 2][4 + (t & 3)];
       }
-      double* out = eslab + ((int64_t)blockIdx.y * L + leaf) * 2;
+      double* out = eslab + ((int64_t)blockIdx.x * L + leaf) * 2;
       out[0] = a;
       out[1] = b;
     }
@@ -293,12 +293,15 @@ int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {
   const int L = a.tree->L, Lp = a.tree->Lp;
   if (a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr) {
     float2* rowstat = const_cast<float2*>(part) + (size_t)a.N * nchunk;     // room reserved by run_streamed
+    BNPVI_REQUIRE(ceil_div(a.N, 4) <= 0x7fffffffLL, "estep: N=%lld exceeds the streamed regime's grid", (long long)a.N);
     hipLaunchKernelGGL(estep_rowstat_kernel, dim3((unsigned)ceil_div(a.N, 4)), dim3(256), 0, a.stream, part,
                        nchunk, a.N, rowstat);
     BNPVI_LAUNCH_CHECK();
+    // row blocks on gridDim.x (2^31 - 1 of them: N < 2^31 * kNormRows), the leaf windows on gridDim.y
     const int64_t rblocks = ceil_div(a.N, kNormRows);
-    BNPVI_REQUIRE(rblocks <= 65535, "estep: %lld row blocks", (long long)rblocks);
-    dim3 grid((unsigned)ceil_div(Lp, 256), (unsigned)rblocks);
+    BNPVI_REQUIRE(rblocks <= 0x7fffffffLL && ceil_div(Lp, 256) <= 65535, "estep: %lld row blocks, %d leaf windows",
+                  (long long)rblocks, (int)ceil_div(Lp, 256));
+    dim3 grid((unsigned)rblocks, (unsigned)ceil_div(Lp, 256));
     if (a.estats) {
       int rc = a.ctx->slabs.ensure((size_t)rblocks * 2 * L * sizeof(double));
       if (rc) return rc;

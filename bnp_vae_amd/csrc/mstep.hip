@@ -334,7 +334,9 @@ int launch_leaf_stats(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi,
   const int W = 1 + D * (want_q ? 2 : 1);
   // the mass rows are accumulated with atomics: they must start at zero (bnpvi_params_prior leaves
   // the buffer it consumed zeroed, so the steady-state iteration needs no memset)
-  if (mass && ctx->mass_clean != mass) BNPVI_HIP(hipMemsetAsync(mass, 0, (size_t)V * L * sizeof(double), s));
+  const bool known_zero = ctx->mass_clean == mass && ctx->mass_clean_elems == (size_t)V * L &&
+                          ctx->mass_clean_stream == s;
+  if (mass && !known_zero) BNPVI_HIP(hipMemsetAsync(mass, 0, (size_t)V * L * sizeof(double), s));
   if (mass) ctx->mass_clean = nullptr;
   if (N == 0) {
     BNPVI_HIP(hipMemsetAsync(stats, 0, (size_t)L * W * sizeof(double), s));

@@ -36,7 +36,7 @@ extern "C" int bnpvi_leaf_stats_noalloc(bnpvi_ctx* ctx, const float* Z, int ldz,
                                         const int32_t* vid, int64_t N, int D, int L, int V, int want_q,
                                         double* stats, double* mass, void* stream) {
   BNPVI_REQUIRE(ctx != nullptr, "bnpvi_leaf_stats_noalloc: ctx is NULL");
-  BNPVI_REQUIRE(N >= 0 && N < (int64_t(1) << 40), "bnpvi_leaf_stats_noalloc: N=%lld", (long long)N);
+  BNPVI_REQUIRE(N >= 0 && N < (int64_t(1) << 33), "bnpvi_leaf_stats_noalloc: N=%lld", (long long)N);
   const int Dp = bnpvi_padded_dim(D);
   BNPVI_REQUIRE(D >= 1 && Dp > 0, "bnpvi_leaf_stats_noalloc: D=%d unsupported (1..256)", D);
   BNPVI_REQUIRE(ldz >= Dp && ldz % 4 == 0,

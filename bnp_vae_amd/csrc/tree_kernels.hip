@@ -727,6 +727,8 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
   ctx->ops_alpha = alpha;
   ctx->ops_D = D;
   ctx->mass_clean = mass;
+  ctx->mass_clean_elems = (size_t)V * t->L;
+  ctx->mass_clean_stream = s;
   return BNPVI_OK;
 }
 
@@ -1190,7 +1192,7 @@ __global__ __launch_bounds__(256) void path_distances_kernel(
 int launch_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz, int64_t N, int D,
                           const double* alpha, const int32_t* assign, int max_depth, int32_t* node_out,
                           double* dist_out, hipStream_t s) {
-  (void)ctx;
+  (void)ctx;                             // N < 2^33 (check_common): the grid fits
   hipLaunchKernelGGL(path_distances_kernel, dim3((unsigned)ceil_div(N, 4)), dim3(256), 0, s, Z, ldz, N, D, alpha,
                      assign, t->d_node_of_leaf, t->d_parent, t->d_depth, t->L, max_depth, node_out, dist_out);
   BNPVI_LAUNCH_CHECK();

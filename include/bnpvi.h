@@ -23,6 +23,11 @@
  *   - vid: int32 [N], index of the frame's video in [0, V) (src/var_inf.py:318-322 does
  *     this lookup with list.index per frame).
  *   - nodes are numbered in PRE-ORDER (the order of get_nodes_list, src/var_inf.py:465-472).
+ *   - sizes: 1 <= D <= 256; N < 2^33 frames in every entry point (each regime's grids and 64-bit row
+ *     offsets hold up to there; BNPVI_EINVAL beyond).  Trees: any K for the M-step and the tree kernels; the
+ *     E-step's streamed regime (more than 64 leaves with hard mode / arg-max, or leaf operands beyond the
+ *     LDS) needs ceil(padded L / 256) <= 65535 leaf windows.  The no-allocation entry point has its own,
+ *     smaller limit (see there).
  */
 #ifndef BNPVI_H
 #define BNPVI_H
@@ -152,7 +157,11 @@ int bnpvi_gamma_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* mass
  * trees all of it is ONE kernel launch, which also prepares the leaf operands of the coming
  * E-step (pass BNPVI_ESTEP_OPERANDS_READY to bnpvi_estep with the same alpha_dev).
  * mass_dev is CONSUMED: it is zeroed once read, which is the state bnpvi_leaf_stats needs it
- * in (its memset is then skipped). */
+ * in.  The context remembers (pointer, V * L, stream) of that buffer and the NEXT bnpvi_leaf_stats
+ * skips its memset only when all three match; any bnpvi_leaf_stats with a mass buffer forgets it.
+ * A caller that writes into the buffer in between, or frees it and allocates another one of the same
+ * size at the same address with other contents on the same stream, breaks that contract -- call
+ * bnpvi_gamma_prior (which does not record the buffer) or zero it yourself in that case. */
 int bnpvi_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* stats_dev,
                        int stats_width, int D, double sigma_b_sqrinv, double sigma_z_sqrinv,
                        const double* alpha0_dev, double* alpha_dev, double* sigma_dev,
