@@ -2,7 +2,8 @@
 per-node ranking of the frames below a node -- what /root/reference/src/create_hierarchy.py
 (:74-91, :40-53) and src/compute_acc_frame_avg_dynamic.py (:49-52) compute from the pickled node
 list with a Python loop per frame.  Here: one hard-mode E-step (arg-min over leaves), one
-path-distance kernel, and a stable device sort.  Image montage / label voting are not reproduced.
+path-distance kernel, and a stable device sort; `class_vote` is the tree-decayed class vote of
+src/compute_acc_frame_avg_dynamic.py:61-129.  The image montage of create_hierarchy.py is not reproduced.
 """
 from __future__ import annotations
 
