@@ -381,3 +381,33 @@ def test_batched_kmeans_seeding_against_oracle(N, D, L, K, sharp):
         np.testing.assert_array_equal(Z[rows[j]].astype(np.float64), want)
     assert single_rows == rows[L // 2]
     np.testing.assert_array_equal(single_centres, centres[L // 2])
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a bare shell (the driver's N > 1 form without a launcher): the parent
+    starts two fresh ranks before anything touches the GPU; on a one-GPU box they rehearse on cuda:0 over
+    gloo and the record says so.  Checks the one-JSON-line contract, not the numbers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=110)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["unit"] == "samples/s" and rec["higher_is_better"] is True and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and abs(rec["value"] - 2 * 999936 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in rec["roofline"]
+    assert "cpu_baseline" not in rec           # rank 0 at N = 1 only
+    strong = rec["config3_strong"]
+    assert strong["scaling"] == "strong" and strong["frames_per_rank"] * 2 == strong["frames_total"]
+    assert strong["allreduce_bytes_per_step"] == 512 * 65 * 8 + 512 * 2 * 8
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert rec["config"]["rehearsal_on_one_gpu"] is True and rec["config"]["collective_backend"] == "gloo"
