@@ -469,6 +469,33 @@ __device__ __forceinline__ void tile_epilogue_soft(const FusedParams& p, int64_t
       }
     }
   }
+#if !defined(BNPVI_ABLATE_NOSTORE) && !defined(BNPVI_PHI_STORE_64B)
+  if (FULL) {
+    // Whole 128-byte lines per store instruction.  A lane holds 16 B of its frame per leaf tile, so the
+    // natural store (below) writes 16 frames x 64 B per instruction and every line is completed by a
+    // second one -- with the non-temporal policy that costs a copy-shaped kernel 13 us per 256 MB
+    // (tools/ubench/stream_patterns: 91.0 against 77.7 us).  Instead the two halves of the frame columns
+    // trade tiles (DPP rotation by 8 inside the 16-lane row): frames 0-7 go out with one instruction
+    // (lanes j < 8: their tile T, lanes j >= 8: tile T+1 of frame j-8), frames 8-15 with the next.
+    const int j = lane & 15;
+    float* base = p.phi + (n - j + (j & 7)) * p.Lp + (j >> 3) * kLT + 4 * kg;
+#pragma unroll
+    for (int T = 0; T + 1 < NT; T += 2) {
+      if (TV > 0 || T < tiles_valid) {
+        f32x4 va, vb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int a = (int)__float_as_uint(lg[T][c]), b = (int)__float_as_uint(lg[T + 1][c]);
+          va[c] = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false));
+          vb[c] = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false));
+        }
+        store_phi4(base + kLT * T, va);
+        store_phi4(base + 8 * p.Lp + kLT * T, vb);
+      }
+    }
+    return;
+  }
+#endif
 #ifdef BNPVI_ABLATE_NOSTORE
   if (ok && lg[0][0] + lg[0][1] == -123.f) {
 #else
@@ -640,12 +667,7 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
     for (int T = 0; T < NT; ++T) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float a = s0[T][r], b = s2[T][r];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-          a += __shfl_xor(a, off);
-          b += __shfl_xor(b, off);
-        }
+        const float a = row16_sum(s0[T][r]), b = row16_sum(s2[T][r]);      // DPP row rotations, no LDS
         if (j == 0) {
           const int leaf = kLT * T + 4 * kg + r;
           atomicAdd(&st_lds[2 * leaf], (double)a);

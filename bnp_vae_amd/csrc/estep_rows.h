@@ -135,6 +135,9 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
     unsigned voff[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) voff[r] = (unsigned)((4 * kg + r) * Lp + c);
+    // whole-line stores of tile pairs (pass 2): row 4 (kg & ~1) + r resp. 4 (kg | 1) + r, leaf tile + (kg & 1)
+    const int dA = (kg & 1) ? kLT - 4 * Lp : 0;
+    const int dB = (kg & 1) ? kLT : 4 * Lp;
 
     // One 64-leaf chunk for the lane's (leaf column, 4 frames): squared distances d[t][pair] and
     // log2-unit logits v[t][pair].  No clamp of d at zero: a negative d is below the
@@ -426,6 +429,38 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
       // direct stores: per instruction the wave writes 4 frame rows x 64 B (16 leaf lanes x 4 B);
       // the other half of each 128-byte line follows with the next leaf tile.  Wave-uniform base
       // (tile row, leaf tile) + a fixed 32-bit lane offset per frame row.
+#ifndef BNPVI_ROWS_STORE_64B
+      // Whole tiles without log phi: two leaf tiles at a time, the lane-group pairs (kg, kg ^ 1) trade them
+      // (v_permlane16_swap) so that an instruction writes whole 128-byte lines: rows 4 (kg & ~1) + r with one
+      // instruction, rows 4 (kg | 1) + r with the next; lanes of even kg carry tile T, of odd kg tile T + 1.
+      // Non-temporal like the fused kernel's (phi is next read after Z has gone by again); with 64-byte
+      // pieces that policy cost +11 %, with whole lines it gains 2 % here and 3 % on the iteration
+      // (config 3, 2M frames: E-step 1.71 -> 1.68 ms, iteration 2.74 -> 2.67 ms).
+      if (full && logphi == nullptr) {
+#pragma unroll
+        for (int t = 0; t < kCT; t += 2) {
+          const int T = ch * kCT + t;
+          if (T < tiles_valid) {
+            float* tb = phi + row0 * Lp + kLT * T;
+            float* tbA = tb + dA;
+            float* tbB = tb + dB;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(pv[t][r >> 1][r & 1]),
+                                                                __float_as_uint(pv[t + 1][r >> 1][r & 1]), false, false);
+#ifndef BNPVI_ROWS_STORE_PLAIN
+              __builtin_nontemporal_store(__uint_as_float(sw[0]), tbA + voff[r]);
+              __builtin_nontemporal_store(__uint_as_float(sw[1]), tbB + voff[r]);
+#else
+              tbA[voff[r]] = __uint_as_float(sw[0]);
+              tbB[voff[r]] = __uint_as_float(sw[1]);
+#endif
+            }
+          }
+        }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int t = 0; t < kCT; ++t) {
         const int T = ch * kCT + t;

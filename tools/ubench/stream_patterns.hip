@@ -3,6 +3,7 @@
 //   pattern 0: 1 KiB contiguous per wave-instruction (lane i -> 16 B at base + 16 i)
 //   pattern 1: 16 rows x 64 B per wave-instruction (lane (j = i & 15, kg = i >> 4) -> row j,
 //              bytes 16 kg of a 64-B piece) -- the MFMA 16x16x32 B-operand footprint
+//   pattern 2: 8 rows x 128 B per wave-instruction (whole 128-B lines)
 // modes: 0 read + reduce, 1 write, 2 copy (read A, write B: the E-step's traffic shape),
 //        3 copy with nontemporal stores, 4 copy with nontemporal loads and stores
 #include <hip/hip_runtime.h>
@@ -31,6 +32,10 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ in, float4* 
   float4 buf[PF][4];
   auto idx = [&](long tile, int i) -> long {
     if (PAT == 0) return tile * 256 + i * 64 + lane;
+    if (PAT == 2) {                              // 8 rows x 128 B per instruction (whole cache lines)
+      const int j8 = lane & 7, h = lane >> 3;
+      return tile * 256 + ((i & 1) * 8 + j8) * 16 + (i >> 1) * 8 + h;
+    }
     const int j = lane & 15, kg = lane >> 4;
     return tile * 256 + j * 16 + i * 4 + kg;     // row j (16 float4 per row), piece i, 16 B kg
   };
@@ -178,10 +183,13 @@ int main(int argc, char** argv) {
     run<1, 0, 2>("read  16x64B     pf2", a, b, ntiles, sink, blocks);
     run<0, 1, 1>("write contiguous", a, b, ntiles, sink, blocks);
     run<1, 1, 1>("write 16x64B", a, b, ntiles, sink, blocks);
+    run<2, 1, 1>("write 8x128B", a, b, ntiles, sink, blocks);
     run<0, 2, 1>("copy  contiguous pf1", a, b, ntiles, sink, blocks);
     run<1, 2, 1>("copy  16x64B     pf1", a, b, ntiles, sink, blocks);
     run<0, 3, 1>("copy  contiguous nt-st", a, b, ntiles, sink, blocks);
     run<1, 3, 1>("copy  16x64B     nt-st", a, b, ntiles, sink, blocks);
+    run<2, 3, 1>("copy  8x128B     nt-st", a, b, ntiles, sink, blocks);
+    run<2, 2, 1>("copy  8x128B     pf1", a, b, ntiles, sink, blocks);
     run<0, 4, 1>("copy  contiguous nt-ld+st", a, b, ntiles, sink, blocks);
     run<1, 4, 1>("copy  16x64B     nt-ld+st", a, b, ntiles, sink, blocks);
   }
