@@ -198,18 +198,24 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   // trusted; the common case is screened with ONE compare per lane (min d^2 against the bound
   // for the largest ||a||^2), the per-entry test runs only for waves that fail the screen.
   const float unscale = -2.f * pow2f(-kz) * lo_.inv_sa;
-  float dmin = INFINITY;
+  // pairs of entries on the packed fp32 pipe: d^2 = max(unscale * acc + (||z||^2 + ||a||^2), 0)
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t un2 = {unscale, unscale}, zz2 = {zz, zz}, zero2 = {0.f, 0.f};
+  f32x2_t dmin2 = {INFINITY, INFINITY};
 #pragma unroll
   for (int T = 0; T < NT; ++T) {
     const float4 aa4 = *reinterpret_cast<const float4*>(lo_.aa + kLT * T + 4 * kg);
-    const float aav[4] = {aa4.x, aa4.y, aa4.z, aa4.w};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float v = fmaxf(fmaf(unscale, acc[T][r], zz + aav[r]), 0.f);
-      dmin = fminf(dmin, v);
-      acc[T][r] = v;
-    }
+    const f32x2_t aaA = {aa4.x, aa4.y}, aaB = {aa4.z, aa4.w};
+    const f32x2_t accA = {acc[T][0], acc[T][1]}, accB = {acc[T][2], acc[T][3]};
+    const f32x2_t vA = __builtin_elementwise_max(un2 * accA + (zz2 + aaA), zero2);
+    const f32x2_t vB = __builtin_elementwise_max(un2 * accB + (zz2 + aaB), zero2);
+    dmin2 = __builtin_elementwise_min(dmin2, __builtin_elementwise_min(vA, vB));
+    acc[T][0] = vA[0];
+    acc[T][1] = vA[1];
+    acc[T][2] = vB[0];
+    acc[T][3] = vB[1];
   }
+  const float dmin = fminf(dmin2[0], dmin2[1]);
   const float snmax = zz + lo_.aamax;
   unsigned pend = 0u;
   if (__builtin_expect(__ballot(dmin < kRefineRel * snmax * snmax) != 0ull, 0)) {
@@ -590,7 +596,8 @@ __global__ __launch_bounds__(kEWaves * 64, fused_min_waves(DP, NT)) void estep_f
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction; said so, the tile counters and loop control live in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int kg = lane >> 4;
   const int64_t ntiles = (N + kFT - 1) / kFT;
@@ -699,7 +706,8 @@ __global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logi
   constexpr int S = DP / 32;
   constexpr int kWaves = WAVES > 0 ? WAVES : kEWaves;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  // wave-uniform by construction; said so, the tile counters and loop control live in scalar registers
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j = lane & 15;
   const int kg = lane >> 4;
   const int chunk = blockIdx.y;
