@@ -411,3 +411,67 @@ def test_bench_launches_its_own_ranks():
     import torch
     if torch.cuda.device_count() < 2:
         assert rec["config"]["rehearsal_on_one_gpu"] is True and rec["config"]["collective_backend"] == "gloo"
+
+
+def test_c_abi_argument_checks_of_round_two():
+    """Error behaviour of the entry points touched in round 2: too many k-means columns per call, the frame-count
+    bound, and the zeroed-mass bookkeeping of bnpvi_params_prior (a mass buffer of another size is memset
+    again; the recorded one is not)."""
+    import ctypes as C
+    import torch
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI, _ptr
+    N, D, bf, levels = 4096, 32, 4, 2
+    rng = np.random.RandomState(0)
+    dev = DeviceVI(device=0)
+    try:
+        parent, is_leaf = [-1], [0]          # regular tree in pre-order
+        def build(depth):
+            me = len(parent) - 1
+            if depth == levels:
+                is_leaf[me] = 1
+                return
+            for _c in range(bf):
+                parent.append(me); is_leaf.append(0)
+                build(depth + 1)
+        build(0)
+        K, L = len(parent), int(sum(is_leaf))
+        Z = rng.normal(size=(N, D)).astype(np.float32)
+        vid = (np.arange(N) // 256).astype(np.int32)
+        V = int(vid[-1]) + 1
+        dev.set_latents(Z, vid, V)
+        dev.set_tree(np.asarray(parent, np.int32), np.asarray(is_leaf, np.uint8), rng.normal(size=(K, D)), np.ones(K))
+        dev.default_gamma()
+        dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+        dev.iteration()
+        torch.cuda.synchronize()
+        # (1) more columns than lanes share a row
+        jmax = int(_lib.lib.bnpvi_kmeans_max_columns(D))
+        assert jmax == 8
+        cols = torch.zeros((jmax + 1,), dtype=torch.int32, device=dev.device)
+        rows = torch.zeros((jmax + 1,), dtype=torch.int64, device=dev.device)
+        score = torch.zeros((jmax + 1,), dtype=torch.float64, device=dev.device)
+        rc = _lib.lib.bnpvi_kmeans_pass_multi(dev.ctx, _ptr(dev.Z), dev.Dp, N, D, _ptr(dev.phi), int(dev.phi.shape[1]),
+                                              L, _ptr(cols), jmax + 1, None, 1, None, _ptr(rows), _ptr(score), None)
+        assert rc != 0 and b"columns" in _lib.lib.bnpvi_last_error()
+        # (2) frame-count bound
+        rc = _lib.lib.bnpvi_leaf_stats(dev.ctx, _ptr(dev.Z), dev.Dp, _ptr(dev.phi), int(dev.phi.shape[1]), _ptr(dev.vid),
+                                       1 << 33, D, L, V, 0, _ptr(dev.stats), _ptr(dev.mass), None)
+        assert rc != 0 and b"2^33" in _lib.lib.bnpvi_last_error()
+        # (3) after params_prior the recorded mass buffer is known to be zero; a buffer of another size
+        #     (here: fewer videos, carved out of the same allocation, deliberately dirty) is zeroed again
+        dev.leaf_stats(want_q=False, want_mass=True)
+        ref_mass = dev.mass.clone()
+        dev.params_prior()                                        # consumes dev.mass, records it as zeroed
+        torch.cuda.synchronize()
+        assert float(dev.mass.abs().max()) == 0.0
+        dev.mass.fill_(7.0)                                       # a caller scribbles over it ...
+        half = N // 2
+        Vh = int(vid[half - 1]) + 1
+        small = dev.mass[:Vh]                                     # ... and passes the same pointer with a smaller V
+        _lib.check(_lib.lib.bnpvi_leaf_stats(dev.ctx, _ptr(dev.Z), dev.Dp, _ptr(dev.phi), int(dev.phi.shape[1]),
+                                             _ptr(dev.vid), half, D, L, Vh, 0, _ptr(dev.stats), _ptr(small), None))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(small.cpu().numpy(), ref_mass[:Vh].cpu().numpy(), rtol=1e-12, atol=1e-12)
+    finally:
+        dev.close()
