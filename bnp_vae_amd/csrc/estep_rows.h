@@ -7,14 +7,15 @@
 // lane (rows 4*(lane>>4) + r).  Consequences:
 //   * per-leaf statistics (S0' = sum phi, S2 = sum phi d^2) need one accumulator per leaf tile
 //     instead of four per frame lane: they are summed over the lane's 4 frames in registers and
-//     added to a workgroup-wide fp32 table in LDS once per (tile, leaf tile);
+//     added with fp64 LDS atomics to a workgroup-wide table once per (tile, leaf tile);
 //   * the softmax runs over lanes and leaf tiles: per frame an ONLINE max / sum-exp over chunks
 //     of 64 leaves (pass 1), combined over the 16 leaf lanes once per frame tile;
 //   * pass 2 recomputes the chunk's logits (MFMAs on the f16 pipe are cheap) and writes
-//     phi = exp2(logit - max) / sum straight from the accumulator layout: one store instruction
-//     covers 4 frame rows x 64 B, the other half of each 128-byte line follows with the next
-//     leaf tile (an LDS staging tile for 16-byte stores measured slower: it serialises the wave
-//     on LDS round trips and caps the workgroup at 8 waves).
+//     phi = exp2(logit - max) / sum from the accumulator layout.  A store instruction of that layout
+//     covers 4 frame rows x 64 B; for whole tiles the lane-group pairs trade two leaf tiles first
+//     (v_permlane16_swap) so that every instruction writes whole 128-byte lines, non-temporal
+//     (an LDS staging tile for 16-byte stores measured slower: it serialises the wave on LDS round
+//     trips and caps the workgroup at 8 waves).
 // HBM traffic is the algorithmic minimum: Z read once, phi written once (no logits round trip).
 #pragma once
 
