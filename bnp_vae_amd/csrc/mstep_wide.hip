@@ -44,6 +44,7 @@ struct WideSlot {
   static constexpr int kPW = kPT / kWideWaves;          // pieces per wave
   static_assert(LBW * DBW == kWideWaves, "4 waves per workgroup");
   static_assert(kPT % kWideWaves == 0, "pieces must divide evenly over the waves");
+  static_assert(kPA % kWideWaves == 0, "a piece index is a phi piece for every wave or for none");
 };
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
@@ -167,7 +168,11 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   const unsigned l15 = (unsigned)(lane & 15);
   // one DMA instruction of a WHOLE k-step: piece q < PW, or (q == PW) the video ids
   auto issue_piece = [&](int q, int64_t f0, float* slot) __attribute__((always_inline)) {
-    if (q < PW)
+    // kPA is a multiple of the wave count, so piece q is a phi piece for every wave or for none: phi streams
+    // past the caches (non-temporal, as in mstep_dma.hip), Z keeps the default policy
+    if (q < PW && q * kWideWaves < Slot::kPA)
+      dma16_nt(src_base[q] + f0 * src_ld[q] + src_off[q], slot + 256 * (wave + kWideWaves * q));
+    else if (q < PW)
       dma16(src_base[q] + f0 * src_ld[q] + src_off[q], slot + 256 * (wave + kWideWaves * q));
     else
       dma4(vid + f0 + l15, slot + Slot::kA + Slot::kB);            // every wave: same 64 bytes, same place
