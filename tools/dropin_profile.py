@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 from bnp_vae_amd import VarInf  # noqa: E402
 
+COMPS = 24          # mixture components of the dynamic workload (--comps=N)
 SHAPES = {
     # name: (N, D, branching, levels, stdev_thr, num_splits, calls, frames per video)
     "config1": (60_000, 32, 5, 2, 1e9, 2, 6, 1000),
@@ -75,7 +76,7 @@ def dropin_calls(name, N, calls, profile, dev):
     if name == "config5":
         g = torch.Generator(device=dev)
         g.manual_seed(7)
-        mu, noise = torch.randn((24, D), generator=g, device=dev) * 3.0, 1.0
+        mu, noise = torch.randn((COMPS, D), generator=g, device=dev) * 3.0, 1.0
     else:
         mu, noise = far_leaf_means(vi, N, FPV, keys, dev), 0.5
     times, ks = [], []
@@ -153,6 +154,11 @@ def run(name, profile):
 
 
 if __name__ == "__main__":
+    for a in sys.argv[1:]:
+        if a.startswith("--comps="):
+            COMPS = int(a.split("=")[1])
+        if a.startswith("--calls="):                      # e.g. --calls=16: a longer dynamic run of config 5
+            SHAPES["config5"] = SHAPES["config5"][:6] + (int(a.split("=")[1]),) + SHAPES["config5"][7:]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     for name in (args or list(SHAPES)):
         run(name, "--profile" in sys.argv)
