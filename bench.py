@@ -181,9 +181,9 @@ class Runner(object):
         dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)            # phi_in = one-hot nearest leaf
 
         def step():
-            dev.iteration(want_estats=want_estats)
-            if want_estats and self.world > 1:
-                dev.allreduce_estats()                               # what split_nodes / merge_nodes read
+            # incl. the all-reduce of the split / merge statistics and, for trees of more than 100 leaves, the
+            # gated S2 pass (src/var_inf.py:217-220)
+            dev.iteration(want_estats=want_estats, n_total=N * self.world)
 
         for _ in range(warmup):
             step()

@@ -16,6 +16,7 @@ OK = 0
 ESTEP_SOFT = 0
 ESTEP_HARD = 1
 ESTEP_OPERANDS_READY = 0x100
+ESTEP_STATS_S0 = 0x200
 
 
 class BnpviError(RuntimeError):
@@ -65,6 +66,9 @@ EXPORTS = {
     "bnpvi_gamma_prior": (_i, [_p, _p, _p, _p, _i, _d, _d, _p, _p, _p]),
     "bnpvi_params_prior": (_i, [_p, _p, _p, _i, _i, _d, _d, _p, _p, _p, _p, _i, _d, _p, _p, _p]),
     "bnpvi_estep": (_i, [_p, _p, _p, _i, _p, _i64, _i, _p, _p, _d, _i, _p, _p, _p, _p, _p]),
+    "bnpvi_split_max_columns": (_i, []),
+    "bnpvi_split_gate": (_i, [_p, _p, _i, _d, _p, _i, _p, _p]),
+    "bnpvi_leaf_s2": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p]),
     "bnpvi_kmeans_pass_multi": (_i, [_p, _p, _i, _i64, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "bnpvi_kmeans_max_columns": (_i, [_i]),
     "bnpvi_path_distances": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _p]),

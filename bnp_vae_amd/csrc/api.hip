@@ -377,7 +377,7 @@ int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z, int ldz,
   int rc = check_common("bnpvi_estep", ctx, N, D, ldz);
   if (rc) return rc;
   BNPVI_REQUIRE(tree && Z && alpha && phi, "bnpvi_estep: NULL argument");
-  const int base_mode = mode & ~BNPVI_ESTEP_OPERANDS_READY;
+  const int base_mode = mode & ~(BNPVI_ESTEP_OPERANDS_READY | BNPVI_ESTEP_STATS_S0);
   BNPVI_REQUIRE(base_mode == BNPVI_ESTEP_SOFT || base_mode == BNPVI_ESTEP_HARD, "bnpvi_estep: mode=%d", mode);
   BNPVI_REQUIRE(base_mode == BNPVI_ESTEP_HARD || (prior && vid),
                 "bnpvi_estep: soft mode needs prior and vid");

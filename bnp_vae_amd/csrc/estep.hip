@@ -374,7 +374,8 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
   int* amax_bits = (int*)(scal + 1);
   const bool ready = (mode & BNPVI_ESTEP_OPERANDS_READY) && ctx->ops_tree == t && ctx->ops_D == D &&
                      ctx->ops_alpha == alpha;
-  mode &= ~BNPVI_ESTEP_OPERANDS_READY;
+  const bool s0_only = (mode & BNPVI_ESTEP_STATS_S0) != 0;
+  mode &= ~(BNPVI_ESTEP_OPERANDS_READY | BNPVI_ESTEP_STATS_S0);
   ctx->ops_tree = nullptr;                      // one use: alpha may change before the next call
   if (ready) {
     // packed by bnpvi_params_prior from this very alpha buffer
@@ -398,7 +399,7 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
     return BNPVI_OK;
   }
   EstepArgs a{ctx, t, Z, ldz, vid, N, apack, aavec, a32, scal, prior, (float)(0.5 * sZ), mode,
-              phi, logphi, assign, estats, s};
+              phi, logphi, assign, estats, s, s0_only};
   switch (DP) {
     case 32: return estep_dispatch<32>(a);
     case 64: return estep_dispatch<64>(a);

@@ -3,7 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "estep_rows.h"
+#include "estep_rows1.h"
 
 #ifndef BNPVI_DP
 #error "compile with -DBNPVI_DP=<padded latent dim>"
@@ -186,6 +186,59 @@ static int run_rows(const EstepArgs& a) {
   return launch_rows<DP, STATS, 0>(a);
 }
 
+// One-pass row kernel (estep_rows1.h): soft mode, no log phi / arg-max, at most Rows1Lds<DP>::max_chunks()
+// chunks of 64 leaves, per-leaf mass as the only statistic (S2 left 0: the caller asked for that with
+// BNPVI_ESTEP_STATS_S0, or for no statistics at all).
+template <int DP, int NCH>
+static int launch_rows1(const EstepArgs& a) {
+  const int L = a.tree->L, Lp = a.tree->Lp;
+  constexpr size_t lds = Rows1Lds<DP>::bytes(NCH);
+  auto k = estep_rows1_kernel<DP, NCH>;
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = (int)((size_t)kMaxLdsBytes / lds);
+  per_cu = per_cu < 1 ? 1 : (per_cu > 16 / kR1Waves ? 16 / kR1Waves : per_cu);     // two waves per SIMD
+  const int64_t ntiles = ceil_div(a.N, kFT);
+  // contiguous tile ranges per workgroup, a multiple of the waves; at most 512 tiles (8192 frames) per
+  // workgroup: its fp64 table takes one fp32 partial per (tile, leaf)
+  int64_t tpw = ceil_div(ntiles, (int64_t)a.ctx->num_cu * per_cu);
+  tpw = round_up((int)(tpw < kR1Waves ? kR1Waves : tpw), kR1Waves);
+  if (tpw > 512) tpw = 512;
+  const int64_t blocks = ceil_div(ntiles, tpw);
+  double* eslab = nullptr;
+  if (a.estats) {
+    int rc = a.ctx->slabs.ensure((size_t)blocks * 2 * L * sizeof(double));
+    if (rc) return rc;
+    eslab = (double*)a.ctx->slabs.ptr;
+  }
+  const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
+  hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kR1Waves * 64), lds, a.stream, a.Z, a.ldz, a.vid, a.N, L, Lp,
+                     a.apack, a.aavec, a.a32, a.scal, a.prior, a.half_sz, a.phi, eslab, (int)tpw);
+  if (timed) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
+  BNPVI_LAUNCH_CHECK();
+  if (a.estats) return estep_reduce_slabs(a, eslab, (int)blocks);
+  return BNPVI_OK;
+}
+
+template <int DP, int NCH>
+static int run_rows1(const EstepArgs& a, int chunks) {
+  if constexpr (NCH < 2) {
+    (void)chunks;
+    set_error("estep: no one-pass row kernel for this shape");
+    return BNPVI_EUNSUPPORTED;
+  } else {
+    if (chunks == NCH) return launch_rows1<DP, NCH>(a);
+    return run_rows1<DP, NCH - 1>(a, chunks);
+  }
+}
+
+template <int DP>
+static bool rows1_fits(const EstepArgs& a) {
+  const int chunks = (int)ceil_div(a.tree->Lp, kLT * kRChunk);
+  return a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr && a.logphi == nullptr &&
+         (a.estats == nullptr || a.s0_only) && chunks >= 2 && chunks <= Rows1Lds<DP>::max_chunks();
+}
+
 template <>
 int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   constexpr int DP = BNPVI_DP;
@@ -193,6 +246,8 @@ int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   const bool hard_stats = a.mode == BNPVI_ESTEP_HARD && a.estats != nullptr;
   const char* force = dev_getenv("BNPVI_ESTEP_PATH");         // development switch: "rows" | "fused"
   const bool want_rows = force ? strcmp(force, "rows") == 0 : Lp > 64;
+  if (Lp > 64 && !force && rows1_fits<DP>(a))
+    return run_rows1<DP, Rows1Lds<DP>::max_chunks()>(a, (int)ceil_div(Lp, kLT * kRChunk));
   if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
     return a.estats ? run_rows<DP, true>(a) : run_rows<DP, false>(a);
   if (!hard_stats) {

@@ -903,6 +903,7 @@ struct EstepArgs {
   int32_t* assign;
   double* estats;
   hipStream_t stream;
+  bool s0_only;        // BNPVI_ESTEP_STATS_S0: estats[l][1] may be left 0
 };
 
 template <int DP> int estep_dispatch(const EstepArgs& a);

@@ -78,6 +78,8 @@ class DeviceVI(object):
         self.Z = self.vid = self.phi = None
         self.alpha = self.sigma = self.gamma = self.mass = self.prior = None
         self.stats = self.estats = self.alpha0 = None
+        self.gate_cols = self.gate_count = self.gate_s2 = None   # split gate: leaves listed, their S2
+        self.s2_gated = False        # the last E-step left S2 to gated_s2()
         self.want_q = False
         self.row_offset = 0          # global index of this rank's first frame
 
@@ -235,9 +237,14 @@ class DeviceVI(object):
                                     self.GAMMA, self.sZ, _ptr(self.gamma), _ptr(self.prior),
                                     self._stream()), "bnpvi_gamma_prior")
 
+    # leaves beyond which the E-step statistics carry S0' only and S2 is computed for the gated leaves alone: the
+    # reference's gate mean(phi) >= 1e-2 (src/var_inf.py:217) admits at most 100 leaves
+    S0_ONLY_FROM = 100
+
     def estep(self, mode=_lib.ESTEP_SOFT, want_logphi=False, want_assign=False, want_stats=True,
-              operands_ready=False):
-        """src/var_inf.py:313-357, 383-393; HARD = one-hot nearest leaf (:126-132)."""
+              operands_ready=False, s0_only=None):
+        """src/var_inf.py:313-357, 383-393; HARD = one-hot nearest leaf (:126-132).
+        s0_only (default: trees of more than 100 leaves): estats[:, 1] is left to `gated_s2`."""
         Lp, L = self.tree.Lp, self.tree.L
         if self.phi is None or tuple(self.phi.shape) != (self.N, Lp):
             self.phi = self._empty((self.N, Lp), torch.float32)
@@ -245,6 +252,11 @@ class DeviceVI(object):
         assign = self._empty((self.N,), torch.int32) if want_assign else None
         if want_stats and (self.estats is None or tuple(self.estats.shape) != (L, 2)):
             self.estats = self._empty((L, 2), torch.float64)
+        if s0_only is None:
+            s0_only = L > self.S0_ONLY_FROM
+        s0_only = bool(s0_only and want_stats and mode == _lib.ESTEP_SOFT)
+        if want_stats:
+            self.s2_gated = s0_only
         if self.N == 0:
             if want_stats:
                 self.estats.zero_()
@@ -252,7 +264,8 @@ class DeviceVI(object):
         check(lib.bnpvi_estep(self.ctx, self.tree.handle, _ptr(self.Z), self.Dp, _ptr(self.vid),
                               self.N, self.D, _ptr(self.alpha),
                               _ptr(self.prior if mode == _lib.ESTEP_SOFT else None), self.sZ,
-                              int(mode) | (_lib.ESTEP_OPERANDS_READY if operands_ready else 0),
+                              int(mode) | (_lib.ESTEP_OPERANDS_READY if operands_ready else 0) |
+                              (_lib.ESTEP_STATS_S0 if s0_only else 0),
                               _ptr(self.phi), _ptr(logphi), _ptr(assign),
                               _ptr(self.estats if want_stats else None), self._stream()),
               "bnpvi_estep")
@@ -274,6 +287,23 @@ class DeviceVI(object):
     def allreduce_estats(self):
         vdist.allreduce_sum_(self.estats, self.group)
 
+    def gated_s2(self, n_total, gate=1e-2):
+        """S2 = sum phi * ||z - alpha||^2 for the leaves whose GLOBAL mass passes the split gate
+        mean(phi) >= gate (src/var_inf.py:217-220); call after `allreduce_estats`.  Everything stays on the
+        device: gate_cols [128] (leaf indices), gate_count [2] (listed, passing), gate_s2 [128]."""
+        cap = int(lib.bnpvi_split_max_columns())
+        if self.gate_cols is None:
+            self.gate_cols = torch.zeros((cap,), dtype=torch.int32, device=self.device)
+            self.gate_count = torch.zeros((2,), dtype=torch.int32, device=self.device)
+            self.gate_s2 = torch.zeros((cap,), dtype=torch.float64, device=self.device)
+        check(lib.bnpvi_split_gate(self.ctx, _ptr(self.estats), self.tree.L, float(gate) * float(n_total),
+                                   _ptr(self.gate_cols), cap, _ptr(self.gate_count), self._stream()),
+              "bnpvi_split_gate")
+        check(lib.bnpvi_leaf_s2(self.ctx, self.tree.handle, _ptr(self.Z), self.Dp, self.N, self.D, _ptr(self.alpha),
+                                _ptr(self.phi), self.tree.Lp, _ptr(self.gate_cols), _ptr(self.gate_count), cap,
+                                _ptr(self.gate_s2), self._stream()), "bnpvi_leaf_s2")
+        vdist.allreduce_sum_(self.gate_s2, self.group)
+
     def params_prior(self):
         """node parameters + gamma-step + prior table (+ leaf operands) in one call."""
         K, Lp = self.tree.K, self.tree.Lp
@@ -289,13 +319,19 @@ class DeviceVI(object):
                                      _ptr(self.sigma), _ptr(self.mass), self.V, self.GAMMA, _ptr(self.gamma),
                                      _ptr(self.prior), self._stream()), "bnpvi_params_prior")
 
-    def iteration(self, want_estats=True):
+    def iteration(self, want_estats=True, n_total=None):
         """One VI iteration: M-step -> gamma-step -> prior table -> E-step (var_inf.py:135-137):
-        statistics pass, the single all-reduce, one mid-step call, E-step."""
+        statistics pass, the single all-reduce, one mid-step call, E-step with the split / merge statistics
+        (for trees of more than 100 leaves: S0' from the E-step, S2 of the gated leaves from `gated_s2`;
+        n_total = frames over all ranks, default this rank's)."""
         self.leaf_stats(want_q=False, want_mass=True)
         self.allreduce_stats()
         self.params_prior()
         self.estep(want_stats=want_estats, operands_ready=True)
+        if want_estats:
+            self.allreduce_estats()                  # what split_nodes / merge_nodes read (no-op on one rank)
+            if self.s2_gated:
+                self.gated_s2(self.N if n_total is None else n_total)
 
     # ------------------------------------------------------------------ split / merge support
     def kmeans_seed(self, col, num_centres, responsibilities=True):

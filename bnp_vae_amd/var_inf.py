@@ -434,11 +434,7 @@ class VarInf(object):
         self._gamma_now_on_device()
         self._retire_internal_phi()
         dev.estep(want_stats=True, operands_ready=True)
-        dev.allreduce_estats()
-        self._adopt_device_phi()
-        self._estats_key = (self._phi_gen, self._phi_ver)
-        self._estats_host = None
-        self._estats_alpha = self._dev_alpha_ver
+        self._after_estep(dev)
 
     def _update_body(self, Z):
         for _iteration in range(1):
@@ -552,12 +548,21 @@ class VarInf(object):
         dev.prior_table()
         self._retire_internal_phi()
         logphi, assign = dev.estep(want_logphi=want_logphi, want_assign=want_assign, want_stats=True)
+        self._after_estep(dev)
+        return logphi, assign
+
+    def _after_estep(self, dev):
+        """The split / merge statistics of the E-step that just ran: S0' (and S2) summed over the ranks; for
+        trees of more than 100 leaves the kernel carried S0' only and S2 is computed now, on the device, for
+        the leaves that pass the reference's mass gate (src/var_inf.py:217) -- the only ones whose stdev
+        split_nodes ever looks at."""
         dev.allreduce_estats()
+        if dev.s2_gated:
+            dev.gated_s2(self._num_frames_global())
         self._adopt_device_phi()
         self._estats_key = (self._phi_gen, self._phi_ver)
         self._estats_host = None
         self._estats_alpha = self._dev_alpha_ver
-        return logphi, assign
 
     # ================================================================== split / merge
     def _leaf_moments(self):
@@ -571,7 +576,17 @@ class VarInf(object):
             self._estats_alpha == self._dev_alpha_ver
         if fresh:
             if self._estats_host is None:
-                self._estats_host = dev.estats.cpu().numpy()
+                est = dev.estats.cpu().numpy()
+                if dev.s2_gated:
+                    # S2 exists for the gated leaves only; NaN elsewhere (split_nodes never reads those)
+                    cnt = dev.gate_count.cpu().numpy()
+                    if int(cnt[1]) > int(cnt[0]):
+                        raise RuntimeError("split gate: %d leaves pass, %d fit one call" % (cnt[1], cnt[0]))
+                    cols = dev.gate_cols.cpu().numpy()[:int(cnt[0])]
+                    s2 = np.full(est.shape[0], np.nan)
+                    s2[cols] = dev.gate_s2.cpu().numpy()[:int(cnt[0])]
+                    est = np.stack([est[:, 0], s2], axis=1)
+                self._estats_host = est
             est = self._estats_host
             return est[:, 0], est[:, 1]
         # phi / alpha did not come from the last E-step: one stats pass with Q = R^T.Z^2

@@ -53,9 +53,13 @@ enum {
   BNPVI_ESTEP_SOFT = 0,   /* softmax responsibilities, src/var_inf.py:313-357,383-393 */
   BNPVI_ESTEP_HARD = 1,   /* one-hot nearest leaf, src/var_inf.py:126-132 (first-call init);
                              same rule as compute_acc_frame_avg_dynamic.py:49-52 */
-  BNPVI_ESTEP_OPERANDS_READY = 0x100  /* OR-ed into the mode: the leaf operands of THIS alpha_dev
+  BNPVI_ESTEP_OPERANDS_READY = 0x100, /* OR-ed into the mode: the leaf operands of THIS alpha_dev
                              were prepared by the preceding bnpvi_params_prior (ignored, and
                              the operands rebuilt, when that is not the case) */
+  BNPVI_ESTEP_STATS_S0 = 0x200        /* OR-ed into the mode: the caller reads only S0' of estats_dev; S2 may be
+                             left 0 (it is, by the one-pass kernel for 64 < L <= 512 leaves) -- the split test's
+                             S2 then comes from bnpvi_split_gate + bnpvi_leaf_s2 for the few leaves that pass
+                             the reference's mass gate (src/var_inf.py:217) */
 };
 
 typedef struct bnpvi_ctx bnpvi_ctx;     /* per-device workspace (partial-sum slabs, scratch) */
@@ -173,13 +177,32 @@ int bnpvi_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* sta
  * phi = softmax over leaves.  alpha_dev: double [K][D] (pre-order).
  *   logphi_dev : float [N][ldphi] or NULL     (log responsibilities)
  *   assign_dev : int32 [N] or NULL            (arg-max leaf, first index on ties)
- *   estats_dev : double [L][2] or NULL        S0' = sum_n phi, S2 = sum_n phi*||z-alpha||^2
+ *   estats_dev : double [L][2] or NULL        S0' = sum_n phi, S2 = sum_n phi*||z-alpha||^2 (left 0 under
+ *                                             BNPVI_ESTEP_STATS_S0 where the kernel does not carry it)
  *                                             (mean(phi) and stdev of src/var_inf.py:194,217-220)
  * mode BNPVI_ESTEP_HARD ignores prior and writes the one-hot nearest-leaf matrix. */
 int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int ldz,
                 const int32_t* vid_dev, int64_t N, int D, const double* alpha_dev,
                 const float* prior_dev, double sigma_z_sqrinv, int mode, float* phi_dev,
                 float* logphi_dev, int32_t* assign_dev, double* estats_dev, void* stream);
+
+/* ---- split statistic behind the mass gate: src/var_inf.py:217-220 ------------------------------
+ * split_nodes computes a leaf's stdev = sqrt(sqrt(S2) / S0') only when mean(phi) >= 1e-2, which at most 100
+ * leaves can pass.  For trees whose E-step kernel carries S0' only (BNPVI_ESTEP_STATS_S0):
+ *   bnpvi_split_gate : cols_dev[0 .. count) = the leaves l (ascending) with estats_dev[2 l] >= min_mass
+ *                      (estats_dev: the E-step's [L][2] table, S0' summed over all ranks; min_mass = 1e-2 * the
+ *                      global frame count for the reference's gate); count_dev[0] = min(number passing, cap),
+ *                      count_dev[1] = number passing (int32 [2]); cap <= bnpvi_split_max_columns() = 128.
+ *   bnpvi_leaf_s2    : s2_dev[j] = sum_n phi[n, cols[j]] * ||z_n - alpha_{cols[j]}||^2 for j < count_dev[0]
+ *                      (direct fp32 differences, fp64 above 2048 frames, fixed summation order), 0 for
+ *                      count_dev[0] <= j < cap.  Rank-local sums: a multi-GPU caller all-reduces s2_dev.
+ * Both read count / cols on the device: no host round trip between the E-step and the statistic. */
+int bnpvi_split_max_columns(void);
+int bnpvi_split_gate(bnpvi_ctx* ctx, const double* estats_dev, int L, double min_mass, int32_t* cols_dev, int cap,
+                     int32_t* count_dev, void* stream);
+int bnpvi_leaf_s2(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int ldz, int64_t N, int D,
+                  const double* alpha_dev, const float* phi_dev, int ldphi, const int32_t* cols_dev,
+                  const int32_t* count_dev, int cap, double* s2_dev, void* stream);
 
 /* ---- weighted farthest-point seeding: src/var_inf.py:23-36, 221-224 ------------------------
  * weighted_kmeans picks num_splits centres among the frames: the first is the arg-max of the weights

@@ -54,6 +54,8 @@ def main():
         ("params_prior", dev.params_prior),
         ("estep", lambda: dev.estep(want_stats=False)),
         ("estep_stats", lambda: dev.estep(want_stats=True)),
+        ("estep_stats_s2", lambda: dev.estep(want_stats=True, s0_only=False)),   # S2 for every leaf in the kernel
+        ("gated_s2", lambda: dev.gated_s2(dev.N)),
         ("estep_logphi", lambda: dev.estep(want_stats=False, want_logphi=True)),
         ("iteration", lambda: dev.iteration(want_estats=False)),
     ]
@@ -78,7 +80,7 @@ def main():
         torch.cuda.synchronize()
         ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.iters))
         out.append("%s=%.1f" % (name, 1e3 * ts[len(ts) // 2]))
-        if name in ("leaf_stats", "leaf_stats_q", "estep", "estep_stats", "estep_logphi"):
+        if name in ("leaf_stats", "leaf_stats_q", "estep", "estep_stats", "estep_stats_s2", "estep_logphi"):
             # the main kernel alone (HIP events recorded around it inside the library)
             _lib.check(_lib.lib.bnpvi_profile_enable(dev.ctx, 1))
             for i in range(args.iters):
