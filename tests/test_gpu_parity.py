@@ -39,6 +39,20 @@ def rows_for(fpv, N):
     return vids, [(v, f) for v in vids for f in lc[v].keys()]
 
 
+def check_gated_s2(S0, S2, want_S2, N):
+    """S2 = sum phi ||z - alpha||^2 against the oracle.  Trees of more than 100 leaves carry it only for the
+    leaves behind the reference's gate mean(phi) >= 1e-2 (src/var_inf.py:217), NaN elsewhere."""
+    S0, S2, want_S2 = np.asarray(S0), np.asarray(S2), np.asarray(want_S2)
+    if len(S0) > 100:
+        gated = S0 / float(N) >= 1e-2
+        near = np.abs(S0 / float(N) - 1e-2) < 1e-6          # a mass on the gate may fall either way in fp32
+        assert np.array_equal(np.isnan(S2)[~near], ~gated[~near])
+        ok = ~np.isnan(S2)
+        np.testing.assert_allclose(S2[ok], want_S2[ok], rtol=1e-4, atol=1e-3)
+    else:
+        np.testing.assert_allclose(S2, want_S2, rtol=1e-4, atol=1e-3)
+
+
 def close_params(got, want, what):
     scale = max(1.0, float(np.max(np.abs(want))))
     np.testing.assert_allclose(got, want, rtol=PARAM_RTOL, atol=PARAM_RTOL * scale, err_msg=what)
@@ -249,18 +263,18 @@ def test_row_kernel_against_oracle(N, D, bf, levels, fpv):
         S0, S2 = vi._leaf_moments()
         d2 = ((Z[:, None, :].astype(np.float64) - np.asarray([l.alpha for l in ora.leaves()])[None]) ** 2).sum(-1)
         np.testing.assert_allclose(S0, po.sum(0), rtol=1e-4, atol=1e-4)
-        np.testing.assert_allclose(S2, (po * d2).sum(0), rtol=1e-4, atol=1e-3)
-    # without log phi (the production call) the same phi must come out
+        check_gated_s2(S0, S2, (po * d2).sum(0), len(Z))
+    # without log phi (the production call: the one-pass kernel for 101 .. 512 leaves, estep_rows1.h) the same
+    # phi must come out, to the rounding of two different summation orders
     vi.compute_phi(Z)
-    np.testing.assert_allclose(snapshot(vi)['phi'], pp, rtol=0, atol=1e-6)
-    # and without statistics: up to 256 leaves (D <= 64) that call takes the single-pass variant
-    # (logits in registers); with statistics (above) the two-pass kernel ran
+    np.testing.assert_allclose(snapshot(vi)['phi'], pp, rtol=0, atol=3e-6)
+    # and without statistics
     dev = vi._dev
     two_pass = dev.phi.clone()
     dev.estep(want_stats=False)
     import torch
     torch.cuda.synchronize()
-    assert float((dev.phi - two_pass).abs().max()) <= 2e-6
+    assert float((dev.phi - two_pass).abs().max()) <= 3e-6
     logphi2, _ = dev.estep(want_stats=False, want_logphi=True)
     np.testing.assert_allclose(logphi2.cpu().numpy()[:, :L], ora.last_log_phi, rtol=0, atol=LOGP_ATOL)
 

@@ -1,0 +1,207 @@
+"""Round-3 GPU parity tests: the one-pass row E-step (estep_rows1.h, S0' as its only statistic) and the split
+statistic behind the reference's mass gate (bnpvi_split_gate + bnpvi_leaf_s2), all through the C ABI, against the
+CPU oracle.  Tolerances are BASELINE.json's (tests/test_gpu_parity.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle.vi_oracle import OracleVarInf, snapshot, make_latent_dict
+from tests.test_gpu_parity import (make_vi, close_params, _regular_case, PHI_ATOL, check_gated_s2)
+
+pytestmark = pytest.mark.gpu
+
+
+def _skewed_case(N, D, bf, levels, fpv, seed, heavy, share):
+    """Regular tree, but `share` of the frames sit in `heavy` of the mixture components: a few leaves hold
+    more than 1 % of the mass each (the split gate fires for them), the rest far less."""
+    L = bf ** levels
+    rng = np.random.RandomState(seed)
+    mu = rng.normal(scale=4.0, size=(L, D))
+    comp = rng.randint(0, L, size=N)
+    nh = int(share * N)
+    comp[:nh] = rng.randint(0, heavy, size=nh)
+    Z = (mu[comp] + 1.5 * rng.normal(size=(N, D))).astype(np.float32)
+    Z = Z[rng.permutation(N)]
+    lc = make_latent_dict(Z, fpv)
+    np.random.seed(seed)
+    ora = OracleVarInf(latent_code_size=D, branching=bf, levels=levels, stdev_thr=1e9)
+    Zm = ora.get_matrix_from_dict(lc)
+    ora.build_initial_tree(); ora.build_video_index(); ora.one_hot_init(Zm)
+    np.random.seed(seed)
+    vi = make_vi(latent_code_size=D, branching=bf, levels=levels, stdev_thr=1e9)
+    Zp = vi.get_matrix_from_dict(lc)
+    vi._build_initial_tree(); vi._one_hot_init(Zp)
+    return ora, vi, Zm
+
+
+@pytest.mark.parametrize("N,D,bf,levels,fpv", [
+    (3000, 64, 8, 3, [100, 57]),      # BASELINE config 3 shape (L = 512): 8 chunks of 64 leaves
+    (2000, 32, 5, 3, [256]),          # L = 125 (padded 128): 2 chunks
+    (1500, 128, 6, 3, [300, 41]),     # L = 216 (padded 224), D = 128: 4 chunks, the last one half filled
+    (2300, 64, 16, 2, [128, 77]),     # L = 256: 4 full chunks
+    (1900, 48, 6, 3, [7]),            # 7-frame videos: every 16-frame tile holds 3 videos (per-frame prior rows)
+    (1700, 200, 11, 2, [90, 3]),      # L = 121, D = 200 -> 256: 2 chunks, 64-register Z fragments
+    (2100, 20, 21, 2, [64]),          # L = 441 (padded 448), D = 20 -> 32: 7 chunks
+])
+def test_one_pass_row_kernel_against_oracle(N, D, bf, levels, fpv):
+    """The production call on trees of 101 .. 512 leaves (compute_phi without log phi): phi and S0' from the
+    one-pass kernel, S2 for the gated leaves from the separate pass; two iterations against the oracle."""
+    ora, vi, Z = _regular_case(N, D, bf, levels, fpv, seed=11)
+    for it in range(2):
+        ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
+        ora.compute_gamma(); vi.compute_gamma()
+        ora.compute_phi(Z); vi.compute_phi(Z)
+        assert vi._dev.s2_gated
+        po, pp = snapshot(ora)['phi'], snapshot(vi)['phi']
+        np.testing.assert_allclose(pp, po, rtol=0, atol=PHI_ATOL)
+        np.testing.assert_allclose(pp.sum(axis=1), 1.0, atol=1e-5)
+        S0, S2 = vi._leaf_moments()
+        d2 = ((Z[:, None, :].astype(np.float64) - np.asarray([l.alpha for l in ora.leaves()])[None]) ** 2).sum(-1)
+        np.testing.assert_allclose(S0, po.sum(0), rtol=1e-4, atol=1e-4)
+        check_gated_s2(S0, S2, (po * d2).sum(0), len(Z))
+    # the padded columns of the device matrix stay zero
+    dev = vi._dev
+    if dev.tree.Lp > dev.tree.L:
+        assert float(dev.phi[:, dev.tree.L:].abs().max()) == 0.0
+
+
+def test_gated_s2_against_oracle_stdev_and_split_decision():
+    """Split-heavy fixture on a 343-leaf tree: 40 % of the frames in 12 components, so a dozen leaves pass
+    mean(phi) >= 1e-2 and the rest do not.  The gated pass must list exactly those leaves, give the
+    reference's stdev for them (OracleVarInf.leaf_stdev, src/var_inf.py:219-220) and split_nodes must take the
+    oracle's decisions and create the same children."""
+    N, D, bf, levels = 6000, 24, 7, 3
+    ora, vi, Z = _skewed_case(N, D, bf, levels, [250, 31], seed=3, heavy=12, share=0.4)
+    ora.num_splits = vi.num_splits = 3
+    for it in range(2):
+        ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
+        ora.compute_gamma(); vi.compute_gamma()
+        ora.compute_phi(Z); vi.compute_phi(Z)
+    dev = vi._dev
+    assert dev.s2_gated
+    leaves = ora.leaves()
+    mean_phi = np.asarray([np.mean(l.phi) for l in leaves])
+    gated = np.nonzero(mean_phi >= 1e-2)[0]
+    assert 5 <= len(gated) <= 40, len(gated)
+    cnt = dev.gate_count.cpu().numpy()
+    assert int(cnt[0]) == int(cnt[1]) == len(gated)
+    np.testing.assert_array_equal(dev.gate_cols.cpu().numpy()[:cnt[0]], gated)
+    S0, S2 = vi._leaf_moments()
+    assert np.array_equal(np.nonzero(~np.isnan(S2))[0], gated)
+    want_sd = np.asarray([ora.leaf_stdev(leaves[j].phi, Z, leaves[j].alpha) for j in gated])
+    got_sd = np.sqrt(np.sqrt(S2[gated]) / S0[gated])
+    np.testing.assert_allclose(got_sd, want_sd, rtol=1e-4)
+    # a threshold between the gated leaves' stdevs: some split, some do not
+    srt = np.sort(want_sd)
+    thr = float(0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]))
+    np.random.seed(5)
+    r_o = ora.split_nodes(ora.root, Z, thr)
+    np.random.seed(5)
+    r_p = vi.split_nodes(vi.root, Z, thr)
+    assert bool(r_o) and bool(r_p)
+    so, sp = snapshot(ora), snapshot(vi)
+    assert list(sp['ids']) == list(so['ids'])
+    np.testing.assert_array_equal(sp['is_leaf'], so['is_leaf'])
+    close_params(sp['alpha'], so['alpha'], 'alpha after split (k-means centres)')
+    np.testing.assert_allclose(sp['phi'], so['phi'], rtol=0, atol=PHI_ATOL)
+
+
+def test_split_gate_and_leaf_s2_raw_abi():
+    """bnpvi_split_gate / bnpvi_leaf_s2 called directly: a gate low enough that more leaves pass than one call
+    lists (count[0] = cap, count[1] = all of them), S2 of the listed leaves against torch fp64, zeros behind
+    them, and argument errors."""
+    import torch
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI, _ptr
+    from bench import regular_tree
+    lib = _lib.lib
+    N, D, L = 5000, 40, 300
+    parent, is_leaf = regular_tree(L, 1)
+    rs = np.random.RandomState(4)
+    alpha = rs.normal(size=(L + 1, D))
+    Z = (alpha[1:][rs.randint(0, L, size=N)] + rs.normal(size=(N, D))).astype(np.float32)
+    dev = DeviceVI(device=0)
+    dev.set_latents(Z, (np.arange(N) // 100).astype(np.int32), (N + 99) // 100)
+    dev.set_tree(parent, is_leaf, alpha, np.ones(L + 1))
+    dev.default_gamma()
+    dev.prior_table()
+    dev.estep(want_stats=True)
+    cap = int(lib.bnpvi_split_max_columns())
+    assert cap == 128
+    cols = torch.full((cap,), -1, dtype=torch.int32, device=dev.device)
+    count = torch.zeros((2,), dtype=torch.int32, device=dev.device)
+    s2 = torch.full((cap,), -5.0, dtype=torch.float64, device=dev.device)
+    S0 = dev.estats[:, 0].cpu().numpy()
+    for min_mass, lim in ((float(np.sort(S0)[L - 37]), cap), (0.0, cap), (float(np.sort(S0)[L - 50]), 16),
+                          (1e30, cap)):
+        _lib.check(lib.bnpvi_split_gate(dev.ctx, _ptr(dev.estats), L, min_mass, _ptr(cols), lim, _ptr(count),
+                                        dev._stream()))
+        _lib.check(lib.bnpvi_leaf_s2(dev.ctx, dev.tree.handle, _ptr(dev.Z), dev.Dp, N, D, _ptr(dev.alpha),
+                                     _ptr(dev.phi), dev.tree.Lp, _ptr(cols), _ptr(count), lim, _ptr(s2),
+                                     dev._stream()))
+        want_cols = np.nonzero(S0 >= min_mass)[0]
+        c = count.cpu().numpy()
+        assert int(c[1]) == len(want_cols) and int(c[0]) == min(len(want_cols), lim)
+        got_cols = cols.cpu().numpy()[:c[0]]
+        np.testing.assert_array_equal(got_cols, want_cols[:c[0]])
+        got = s2.cpu().numpy()
+        assert np.all(got[c[0]:lim] == 0.0)
+        if c[0]:
+            idx = torch.from_numpy(got_cols).long().to(dev.device)
+            A = dev.alpha[torch.from_numpy(dev.tree.node_of_leaf[got_cols]).long().to(dev.device)].float().double()
+            d2 = ((dev.Z[:, None, :D].double() - A[None]) ** 2).sum(-1)
+            want = (dev.phi[:, idx].double() * d2).sum(0).cpu().numpy()
+            np.testing.assert_allclose(got[:c[0]], want, rtol=1e-5)
+    # bit-reproducible
+    first = s2.clone()
+    for _ in range(20):
+        _lib.check(lib.bnpvi_leaf_s2(dev.ctx, dev.tree.handle, _ptr(dev.Z), dev.Dp, N, D, _ptr(dev.alpha),
+                                     _ptr(dev.phi), dev.tree.Lp, _ptr(cols), _ptr(count), cap, _ptr(s2),
+                                     dev._stream()))
+        assert torch.equal(s2, first)
+    # argument checks
+    assert lib.bnpvi_split_gate(dev.ctx, _ptr(dev.estats), L, 0.0, _ptr(cols), cap + 1, _ptr(count),
+                                dev._stream()) == 1
+    assert lib.bnpvi_leaf_s2(dev.ctx, dev.tree.handle, _ptr(dev.Z), dev.Dp, N, D, _ptr(dev.alpha), _ptr(dev.phi),
+                             dev.tree.Lp + 32, _ptr(cols), _ptr(count), cap, _ptr(s2), dev._stream()) == 1
+    assert lib.bnpvi_leaf_s2(dev.ctx, dev.tree.handle, _ptr(dev.Z), dev.Dp, N, D, _ptr(dev.alpha), _ptr(dev.phi),
+                             dev.tree.Lp, C.c_void_p(0), _ptr(count), cap, _ptr(s2), dev._stream()) == 1
+    dev.close()
+
+
+def test_one_pass_kernel_bit_reproducible_and_full_size():
+    """Config-3 shape at 1M frames: softmax rows, total mass, S0' against the column sums of phi, and 100
+    launches with bit-identical phi and statistics equal to 1e-12."""
+    import torch
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    from bench import regular_tree, make_latents
+    N, D = 1_000_003, 64
+    parent, is_leaf = regular_tree(8, 3)
+    K, L = len(parent), int(is_leaf.sum())
+    dev = DeviceVI(device=0)
+    Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
+    dev.set_latents(Z, vid, V)
+    dev.set_tree(parent, is_leaf, np.random.RandomState(13).normal(size=(K, D)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    for _ in range(2):
+        dev.iteration(want_estats=True)
+    assert dev.s2_gated
+    rows = dev.phi[:, :L].sum(dim=1)
+    assert float((rows - 1).abs().max()) < 1e-5
+    S0 = dev.estats[:, 0]
+    assert abs(float(S0.sum()) - N) < 1e-3 * N ** 0.5
+    col = dev.phi[:, :L].double().sum(dim=0)
+    assert float(((S0 - col).abs() / (col + 1.0)).max()) < 1e-6
+    assert float(dev.estats[:, 1].abs().max()) == 0.0
+    first, est0 = None, None
+    for _ in range(100):
+        dev.estep(want_stats=True)
+        if first is None:
+            first, est0 = dev.phi.clone(), dev.estats.clone()
+        else:
+            assert torch.equal(dev.phi, first)
+            assert float(((dev.estats - est0).abs() / (est0.abs() + 1.0)).max()) < 1e-12
+    dev.close()
