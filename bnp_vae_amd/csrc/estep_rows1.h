@@ -148,7 +148,11 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
       for (int t = 0; t < kCT; ++t) {
 #pragma unroll
         for (int r = 0; r < kPR; ++r)
+#ifdef BNPVI_R1_ABLATE_NOPRIOR
+          prv[t][r] = -0.001f * (ch * kCT + t);
+#else
           prv[t][r] = (ch == NCH - 1 && t >= 2) ? prow[r][last_off + kLT * (t - 2)] : prow[r][kLT * (ch * kCT + t)];
+#endif
       }
       const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
       f32x4 acc[kCT];
@@ -306,6 +310,12 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
       stA[r] = stP[r] + ((kgl & 1) ? kLT - 4 * Lp : 0);
       stB[r] = stP[r] + ((kgl & 1) ? kLT : 4 * Lp);
     }
+    bool okA[4], okB[4];                                        // rows 4 (kg & ~1) + r, 4 (kg | 1) + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      okA[r] = row0 + 4 * (kg & ~1) + r < N;
+      okB[r] = row0 + 4 * (kg | 1) + r < N;
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       {
@@ -328,6 +338,20 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
           const float tot = __uint_as_float(w[0]) + __uint_as_float(w[1]);   // lane group kg: tile kg
           atomicAdd(st_lane + kLT * kCT * ch, (double)tot);     // padded leaves: adds of 0 to slots nobody reads
         }
+        // lane-group pairs trade two leaf tiles (v_permlane16_swap, in place) so that every store instruction
+        // writes whole 128-byte lines: lanes of even kg carry tile t, of odd kg tile t + 1
+#pragma unroll
+        for (int t = 0; t < kCT; t += 2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(pv[t][r]),
+                                                              __float_as_uint(pv[t + 1][r]), false, false);
+            pv[t][r] = __uint_as_float(sw[0]);
+            pv[t + 1][r] = __uint_as_float(sw[1]);
+          }
+#ifdef BNPVI_R1_ABLATE_NOSTORE
+        if (pv[0][0] == -123.f)
+#endif
         if (full) {
 #pragma unroll
           for (int t = 0; t < kCT; t += 2) {
@@ -335,21 +359,27 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
             if (!(ch == NCH - 1 && t >= 2 && last_half)) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                const u32x2 sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(pv[t][r]),
-                                                                  __float_as_uint(pv[t + 1][r]), false, false);
-                __builtin_nontemporal_store(__uint_as_float(sw[0]), stA[r] + kLT * T);
-                __builtin_nontemporal_store(__uint_as_float(sw[1]), stB[r] + kLT * T);
+#ifdef BNPVI_R1_STORE_PLAIN
+                stA[r][kLT * T] = pv[t][r];
+                stB[r][kLT * T] = pv[t + 1][r];
+#else
+                __builtin_nontemporal_store(pv[t][r], stA[r] + kLT * T);
+                __builtin_nontemporal_store(pv[t + 1][r], stB[r] + kLT * T);
+#endif
               }
             }
           }
         } else {
+          // ragged last tile of the data set: the same traded values, rows past N masked
 #pragma unroll
-          for (int t = 0; t < kCT; ++t) {
+          for (int t = 0; t < kCT; t += 2) {
             const int T = ch * kCT + t;
             if (!(ch == NCH - 1 && t >= 2 && last_half)) {
 #pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (okr[r]) stP[r][kLT * T] = pv[t][r];
+              for (int r = 0; r < 4; ++r) {
+                if (okA[r]) stA[r][kLT * T] = pv[t][r];
+                if (okB[r]) stB[r][kLT * T] = pv[t + 1][r];
+              }
             }
           }
         }
