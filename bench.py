@@ -129,25 +129,79 @@ def cpu_baseline(D, bf, levels, sample_n):
 
 # ---------------------------------------------------------------------------------------------
 def launch_children(args):
-    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this parent has
-    not imported torch and never touches a GPU) and relay rank 0's JSON line."""
+    """`python bench.py --gpus N` from a bare shell: start N fresh rank processes (this parent has not imported
+    torch and never touches a GPU), watch ALL of them, and relay rank 0's JSON line.
+
+    Fail-safe: the parent polls every child; as soon as one exits non-zero (a rank that dies before or inside
+    init_process_group would otherwise leave the others waiting for the rendezvous until the caller's timeout)
+    the rest are terminated, every rank's stderr is kept in its own file and the tails of the failed ranks' are
+    shown, and the parent exits non-zero.  BNPVI_BENCH_LOGDIR names the directory of the per-rank logs
+    (default: a fresh temporary directory, removed when every rank succeeded)."""
+    import shutil
     import socket
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    logdir = os.environ.get("BNPVI_BENCH_LOGDIR")
+    own_logdir = not logdir
+    if own_logdir:
+        logdir = tempfile.mkdtemp(prefix="bnpvi_bench_")
+    os.makedirs(logdir, exist_ok=True)
+    procs, files = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        out = open(os.path.join(logdir, "rank%d.out" % r), "w+")
+        err = open(os.path.join(logdir, "rank%d.err" % r), "w+")
+        files.append((out, err))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=out, stderr=err, text=True))
+    deadline = time.time() + float(os.environ.get("BNPVI_BENCH_TIMEOUT", "3000"))
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = "rank %d exited with code %d" % (bad[0], codes[bad[0]])
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.time() > deadline:
+            failed = "timeout"
+            break
+        time.sleep(0.05)
+    if failed:
+        for p in procs:                       # fresh children of this parent only, by their exact PIDs
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    codes = [p.returncode for p in procs]
+    files[0][0].seek(0)
+    sys.stdout.write(files[0][0].read())
     sys.stdout.flush()
-    return max(abs(c) for c in codes)
+    if failed:
+        sys.stderr.write("bench.py: %s; the other ranks were terminated (exit codes %s); per-rank logs in %s\n"
+                         % (failed, codes, logdir))
+        for r, (_o, e) in enumerate(files):
+            if codes[r] not in (0, -15):
+                e.seek(0)
+                tail = e.read().strip().splitlines()[-12:]
+                sys.stderr.write("---- rank %d stderr (tail) ----\n%s\n" % (r, "\n".join(tail)))
+    for o, e in files:
+        o.close()
+        e.close()
+    if own_logdir and not failed:
+        shutil.rmtree(logdir, ignore_errors=True)
+    return 1 if failed else 0
 
 
 class Runner(object):
@@ -239,6 +293,7 @@ class Runner(object):
             "N": N, "D": D, "bf": bf, "K": K, "L": L, "V": V, "ms_per_step": ms_per_step,
             "value": N * self.world / (elapsed / steps),
             "allreduce_bytes_per_step": (L * (1 + D) * 8 + (L * 2 * 8 if want_estats else 0)) if self.world > 1 else 0,
+            "ranks_seen": int(self.dist.get_world_size()) if self.world > 1 else 1,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_measured_at_N": traffic_at,
@@ -274,6 +329,9 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
 
+    if os.environ.get("BNPVI_BENCH_FAIL_RANK") == str(rank) and world > 1:
+        raise RuntimeError("rank %d: failure injected by BNPVI_BENCH_FAIL_RANK (watchdog rehearsal)" % rank)
+
     _n, D, bf, levels = CONFIGS[args.config]
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -282,9 +340,16 @@ def main():
     import torch
     import torch.distributed as dist
 
-    # Rehearsal on a box with fewer GPUs than ranks (never a measured configuration): every rank on
-    # cuda:0, gloo with host-staged collectives.  Forced with BNPVI_BENCH_REHEARSAL=1.
-    rehearsal = world > 1 and (os.environ.get("BNPVI_BENCH_REHEARSAL") == "1" or torch.cuda.device_count() < world)
+    # Rehearsal of the N > 1 control flow on one GPU (never a measured configuration; only with
+    # BNPVI_BENCH_REHEARSAL=1): every rank on cuda:0, gloo with host-staged collectives.  Its record says
+    # n_gpus = 1 and value = null; the rate the ranks reached together is kept as `rehearsal_value`.
+    rehearsal = world > 1 and os.environ.get("BNPVI_BENCH_REHEARSAL") == "1"
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
+        if rank == 0:
+            print("bench.py: --gpus %d but only %d GPU(s) visible (BNPVI_BENCH_REHEARSAL=1 rehearses the N > 1 "
+                  "control flow on one GPU over gloo; it is never a measurement)" % (world, torch.cuda.device_count()),
+                  file=sys.stderr)
+        sys.exit(3)
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -321,12 +386,15 @@ def main():
                               % (rec["N"] * world, world, rec["N"], rec["D"], rec["K"], rec["L"]),
                   "frames_total": rec["N"] * world, "frames_per_rank": rec["N"], "steps": s3, "scaling": "strong",
                   "ms_per_step": rec["ms_per_step"], "value": rec["value"], "unit": "samples/s",
-                  "allreduce_bytes_per_step": rec["allreduce_bytes_per_step"], "roofline": rec["roofline"]}
+                  "allreduce_bytes_per_step": rec["allreduce_bytes_per_step"], "ranks_seen": rec["ranks_seen"],
+                  "collective_backend": backend, "rehearsal_on_one_gpu": bool(rehearsal),
+                  "roofline": rec["roofline"]}
 
     if rank == 0:
         out = {
             "metric": "latent samples/sec per VI E+M iteration (whole node)",
-            "value": head["value"], "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "value": None if rehearsal else head["value"], "unit": "samples/s",
+            "n_gpus": 1 if rehearsal else world, "ranks": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: N=%d frames/rank, D=%d, %d-ary tree K=%d nodes L=%d leaves, "
@@ -336,10 +404,15 @@ def main():
                        "parallelism": "sample-sharded x%d; per step 1 fp64 all-reduce of L x (1+D) leaf statistics"
                                       " + 1 of L x 2 split/merge statistics" % world,
                        "collective_backend": backend, "rehearsal_on_one_gpu": bool(rehearsal),
-                       "allreduce_bytes_per_step": head["allreduce_bytes_per_step"]},
+                       "allreduce_bytes_per_step": head["allreduce_bytes_per_step"],
+                       "ranks_seen": head["ranks_seen"]},
             "roofline": head["roofline"],
         }
+        if rehearsal:
+            out["rehearsal_value"] = head["value"]
         if strong is not None:
+            if rehearsal:
+                strong["rehearsal_value"], strong["value"] = strong["value"], None
             out["config3_strong"] = strong
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -50,8 +50,12 @@ extern "C" int bnpvi_leaf_stats_noalloc(bnpvi_ctx* ctx, const float* Z, int ldz,
   // the kernels take the slab base as an argument, exactly as in bnpvi_leaf_stats; here it is the
   // per-device address of `scratch`.  Every slab element a launch reads it has written in the same
   // launch, so nothing has to start at zero (the per-video masses, an OUTPUT of the caller, are
-  // cleared with hipMemsetAsync as in bnpvi_leaf_stats).  The HIP-event timers of the measurement
-  // hooks create events on first use, so they stay off for this call.
+  // cleared with hipMemsetAsync -- ALWAYS here: the "bnpvi_params_prior left this buffer zeroed"
+  // shortcut of bnpvi_leaf_stats is decided from host-side context state, which a captured graph
+  // would freeze at capture time and then accumulate into the masses on every replay).  The
+  // HIP-event timers of the measurement hooks create events on first use, so they stay off for
+  // this call.
+  ctx->mass_clean = nullptr;
   const bool was_profiling = ctx->profiling;
   ctx->profiling = false;
   ctx->slab_override = ctx->static_scratch;

@@ -802,7 +802,8 @@ __device__ inline bool better64(double s, long long r, double bs, long long br) 
 
 // fp32 phi at or above this is a candidate for the saturated-tie rule below (1 - 1e-5)
 constexpr float kSatCandidate = 0.99999f;
-// the fp32 arg-max counts as saturated from here on (1 - 2e-7: 1.0 or one of its two lower neighbours)
+// the fp32 arg-max counts as saturated from here on: 1.0f - 2e-7f rounds to 1 - 3 ulp(1 - 2^-24 spacing), i.e.
+// 1.0 or one of its three lower neighbours
 constexpr float kSaturated = 1.0f - 2e-7f;
 
 // First centres (src/var_inf.py:29-30): arg-max of each of the J phi columns, lowest row on ties.  On

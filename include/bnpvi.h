@@ -105,8 +105,12 @@ int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* p
 
 /* ---- the same data pass for callers that cannot allocate ----------------------------------
  * No counterpart in the reference.  For callers that cannot call hipMalloc: code under HIP graph
- * capture, tight serving loops, harnesses that forbid allocation.  Same arguments, kernels and
- * results (bit for bit) as bnpvi_leaf_stats, but the partial-sum slabs of the launch live in a
+ * capture, tight serving loops, harnesses that forbid allocation.  Same arguments and kernels as
+ * bnpvi_leaf_stats; the results are bit-identical to it while the launch geometry is the same, and equal to
+ * fp32 partial-sum rounding (about 2e-6 relative, still reproducible run to run) when the 32 MiB cap makes
+ * the launch use fewer workgroups with longer frame chunks.  The per-video masses are always cleared by the
+ * call itself (no reliance on bnpvi_params_prior having left them zeroed: safe to replay from a captured
+ * graph).  The partial-sum slabs of the launch live in a
  * static device array of the library (32 MiB per GPU, held until the process ends) instead of the
  * context's grow-only workspace, and the call makes no hipMalloc / hipFree / allocating library
  * call.  A launch that needs more than the array holds (workgroups x L x (1 + D (+ D)) doubles;

@@ -384,34 +384,77 @@ def test_batched_kmeans_seeding_against_oracle(N, D, L, K, sharp):
     np.testing.assert_array_equal(single_centres, centres[L // 2])
 
 
+def _bare_env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` from a bare shell (the driver's N > 1 form without a launcher): the parent
-    starts two fresh ranks before anything touches the GPU; on a one-GPU box they rehearse on cuda:0 over
-    gloo and the record says so.  Checks the one-JSON-line contract, not the numbers."""
+    starts two fresh ranks before anything touches the GPU.  On a one-GPU box this runs as an explicit
+    rehearsal (BNPVI_BENCH_REHEARSAL=1: both ranks on cuda:0 over gloo) whose record says n_gpus = 1 and
+    value = null; without the switch the command refuses instead of passing a one-GPU run off as two.
+    Checks the one-JSON-line contract, not the numbers."""
     import json
     import subprocess
     import sys
+    import torch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = {k: v for k, v in os.environ.items()
-           if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
-                         cwd=root, env=env, capture_output=True, text=True, timeout=110)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    one_gpu = torch.cuda.device_count() < 2
+    if one_gpu:
+        refused = subprocess.run(cmd, cwd=root, env=_bare_env(), capture_output=True, text=True, timeout=110)
+        assert refused.returncode != 0 and "BNPVI_BENCH_REHEARSAL" in refused.stderr
+        assert not [l for l in refused.stdout.splitlines() if l.startswith("{")]
+    out = subprocess.run(cmd, cwd=root, env=_bare_env(**({"BNPVI_BENCH_REHEARSAL": "1"} if one_gpu else {})),
+                         capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["ranks"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
     assert rec["unit"] == "samples/s" and rec["higher_is_better"] is True and rec["scaling"] == "weak"
-    assert rec["value"] > 0 and abs(rec["value"] - 2 * 999936 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * rec["value"]
+    value = rec["rehearsal_value"] if one_gpu else rec["value"]
+    assert value > 0 and abs(value - 2 * 999936 / (rec["ms_per_step"] * 1e-3)) < 1e-6 * value
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in rec["roofline"]
     assert "cpu_baseline" not in rec           # rank 0 at N = 1 only
     strong = rec["config3_strong"]
     assert strong["scaling"] == "strong" and strong["frames_per_rank"] * 2 == strong["frames_total"]
     assert strong["allreduce_bytes_per_step"] == 512 * 65 * 8 + 512 * 2 * 8
-    import torch
-    if torch.cuda.device_count() < 2:
+    assert rec["config"]["ranks_seen"] == 2 and strong["ranks_seen"] == 2
+    if one_gpu:
+        assert rec["n_gpus"] == 1 and rec["value"] is None and strong["value"] is None
         assert rec["config"]["rehearsal_on_one_gpu"] is True and rec["config"]["collective_backend"] == "gloo"
+        assert strong["collective_backend"] == "gloo"
+    else:
+        assert rec["n_gpus"] == 2 and rec["config"]["collective_backend"] == "nccl"
+
+
+def test_bench_watchdog_ends_all_ranks_when_one_fails():
+    """A rank that dies before the rendezvous (BNPVI_BENCH_FAIL_RANK) must not leave the others waiting: the
+    parent notices the first non-zero exit, terminates the rest, exits non-zero within seconds, prints no JSON
+    line and keeps every rank's stderr in a file of its own."""
+    import subprocess
+    import sys
+    import tempfile
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as logdir:
+        t0 = time.time()
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1"],
+                             cwd=root, env=_bare_env(BNPVI_BENCH_REHEARSAL="1", BNPVI_BENCH_FAIL_RANK="1",
+                                                     BNPVI_BENCH_LOGDIR=logdir),
+                             capture_output=True, text=True, timeout=110)
+        took = time.time() - t0
+        assert out.returncode != 0
+        assert took < 60, took
+        assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert "rank 1 exited with code" in out.stderr and "failure injected" in out.stderr
+        assert sorted(os.listdir(logdir)) == ["rank%d.%s" % (r, x) for r in range(3) for x in ("err", "out")]
+        assert "failure injected" in open(os.path.join(logdir, "rank1.err")).read()
 
 
 def test_c_abi_argument_checks_of_round_two():
