@@ -345,10 +345,11 @@ def main():
     # n_gpus = 1 and value = null; the rate the ranks reached together is kept as `rehearsal_value`.
     rehearsal = world > 1 and os.environ.get("BNPVI_BENCH_REHEARSAL") == "1"
     if world > 1 and not rehearsal and torch.cuda.device_count() < world:
-        if rank == 0:
-            print("bench.py: --gpus %d but only %d GPU(s) visible (BNPVI_BENCH_REHEARSAL=1 rehearses the N > 1 "
-                  "control flow on one GPU over gloo; it is never a measurement)" % (world, torch.cuda.device_count()),
-                  file=sys.stderr)
+        # every rank says so (each has its own stderr file under the self-launching parent, which shows the tail
+        # of the first rank to fail)
+        print("bench.py: --gpus %d but only %d GPU(s) visible (BNPVI_BENCH_REHEARSAL=1 rehearses the N > 1 "
+              "control flow on one GPU over gloo; it is never a measurement)" % (world, torch.cuda.device_count()),
+              file=sys.stderr)
         sys.exit(3)
     if rehearsal:
         local_rank = 0

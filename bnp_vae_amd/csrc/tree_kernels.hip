@@ -800,21 +800,22 @@ __device__ inline bool better64(double s, long long r, double bs, long long br) 
   return (s > bs) || (s == bs && r < br);
 }
 
-// fp32 phi at or above this is a candidate for the saturated-tie rule below (1 - 1e-5)
-constexpr float kSatCandidate = 0.99999f;
-// the fp32 arg-max counts as saturated from here on: 1.0f - 2e-7f rounds to 1 - 3 ulp(1 - 2^-24 spacing), i.e.
-// 1.0 or one of its three lower neighbours
-constexpr float kSaturated = 1.0f - 2e-7f;
+// fp32 phi at or above this makes a frame a candidate for the fp64 ordering below.  At most one leaf of a frame
+// can hold more than half of its mass, so every row is summed at most once per pass.
+constexpr float kDominant = 0.5f;
 
-// First centres (src/var_inf.py:29-30): arg-max of each of the J phi columns, lowest row on ties.  On
-// well-separated data many frames have phi = 1 - c with c below fp32 resolution -- they all tie at
-// exactly 1.0 in the fp32 matrix, while the reference's fp64 phi = 1 / (1 + c) still orders them
-// (c = the frame's responsibility mass on all OTHER leaves, which fp32 holds to full relative
-// precision).  So next to the fp32 arg-max every column also tracks the arg-max of the fp64
-// 1 / (1 + c) over its candidate frames (fp32 phi >= 1 - 1e-5; c summed in fp64 over the row without the
-// column itself: no cancellation); the final kernel takes the fp64 winner when the fp32 maximum is
-// saturated.  One wave per row, lane j < J owns column cols[j].  L == 0: the columns are plain weights, not
-// rows of responsibilities -- fp32 arg-max only.
+// First centres (src/var_inf.py:29-30): arg-max of each of the J phi columns, lowest row on ties.  The
+// reference takes it over fp64 responsibilities; the device matrix is fp32, where frames whose fp64 phi differ
+// by less than 6e-8 read the same -- all the frames at exactly 1.0 on well-separated data, but also two frames
+// at 0.99976906 and 0.99976901 (found by the regime-walk trajectory test).  For a frame dominated by the leaf,
+// phi = 1 / (1 + c) with c = the frame's mass on all OTHER leaves, which fp32 holds to full RELATIVE precision:
+// the error of that phi is ~1e-7 * c instead of ~6e-8.  So next to the fp32 arg-max every column tracks the
+// arg-max of the fp64 1 / (1 + c) over its dominated frames (fp32 phi >= 0.5; c summed in fp64 over the row
+// without the column itself: no cancellation), and the final kernel takes that winner whenever there is one --
+// the true maximum is then among those frames.  Below 0.5 the fp32 arg-max stands (its ties are near-ties of
+// the reference's own arithmetic).  Assumes rows that sum to 1 (phi straight from an E-step): callers pass
+// L = 0 otherwise.  One wave per row, lane j < J owns column cols[j].  L == 0: the columns are plain weights,
+// not rows of responsibilities -- fp32 arg-max only.
 __global__ __launch_bounds__(256) void kmeans_first_multi_kernel(const float* __restrict__ phi, int ldphi,
                                                                  int64_t N, int L,
                                                                  const int32_t* __restrict__ cols, int J,
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(256) void kmeans_first_multi_kernel(const float* __
       b32.score = wn;
       b32.row = n;
     }
-    unsigned long long mask = __ballot(L > 0 && lane < J && wn >= kSatCandidate);
+    unsigned long long mask = __ballot(L > 0 && lane < J && wn >= kDominant);
     while (mask != 0ull) {                                     // wave-uniform
       const int jl = __ffsll((long long)mask) - 1;
       mask &= mask - 1ull;
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void kmeans_first_multi_kernel(const float* __
   }
 }
 
-// one workgroup per column j: reduce the partials, apply the saturated-tie rule (part64 != nullptr)
+// one workgroup per column j: reduce the partials; the fp64 winner over the dominated frames stands when there is one
 __global__ __launch_bounds__(256) void kmeans_final_multi_kernel(const Best* __restrict__ part32,
                                                                  const Best64* __restrict__ part64, int nparts,
                                                                  int J, int64_t* __restrict__ best_row,
@@ -907,7 +908,7 @@ __global__ __launch_bounds__(256) void kmeans_final_multi_kernel(const Best* __r
   if (threadIdx.x == 0) {
     const Best w32 = sh32[0];
     const Best64 w64 = sh64[0];
-    if (part64 != nullptr && w32.score >= kSaturated && w64.score >= 0.0) {
+    if (part64 != nullptr && w64.score >= 0.0) {
       best_row[j] = w64.row;
       best_score[j] = w64.score;
     } else {

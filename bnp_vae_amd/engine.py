@@ -346,10 +346,11 @@ class DeviceVI(object):
         Z per centre index for all of them; the arg-max rows feed the next pass's centres through a device
         gather, the host waits once at the end (single process) or exchanges one small table per pass.
 
-        First centres = arg-max of the column.  On well-separated data many frames have phi = 1 - c with c
-        below fp32 resolution: in the fp32 matrix they all tie at exactly 1.0, while the reference's fp64
-        phi = 1 / (1 + c) still orders them; the kernel resolves a saturated maximum that way
-        (`responsibilities=False`: the columns are plain weights, not rows of a softmax -- fp32 arg-max only).
+        First centres = arg-max of the column.  Frames whose fp64 phi differ by less than fp32 resolution tie in
+        the fp32 matrix (all those at exactly 1.0 on well-separated data) while the reference's fp64
+        phi = 1 / (1 + c) still orders them; among the frames the leaf dominates the kernel takes the arg-max
+        over that fp64 form (`responsibilities=False`: the columns are plain weights, or rows that do not sum
+        to 1 -- fp32 arg-max only).
 
         Returns (rows [J][num_centres] -- global indices under a process group --, centres
         [J][num_centres][D] fp64)."""

@@ -632,7 +632,7 @@ class VarInf(object):
             # index for all leaves) and the children are created afterwards, in the walk's order -- which
             # also keeps the order of Node.__init__'s np.random draws
             best_K = self.num_splits
-            # the saturated-tie rule of the first centre (fp64 order of frames whose fp32 phi all read 1.0) assumes
+            # the fp64 ordering of the first centre's candidates (frames that tie in the fp32 matrix) assumes
             # rows that sum to 1, i.e. a phi matrix straight from an E-step; after a prune without E-step, or on
             # caller-assigned phi, the plain fp32 arg-max is used (parity on exact fp32 ties is unpinned there)
             rows_sum_to_one = self._estats_key == (self._phi_gen, self._phi_ver)

@@ -217,11 +217,13 @@ int bnpvi_leaf_s2(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, in
  * so the leaves of one walk share the passes over Z.  cols_dev[J] = the leaves' phi columns (int32,
  * device); J <= bnpvi_kmeans_max_columns(D) (the padded D / 4 lanes that share a row each own a column).
  *   centres_dev == NULL : first centres = arg-max of each column (phi_dev [N][ldphi]), lowest row on
- *                         ties (np.argmax).  With L > 0 the columns are rows of responsibilities over L
- *                         leaves and a saturated fp32 maximum (>= 1 - 2e-7: many frames tie at 1.0 where
- *                         the reference's fp64 phi still orders them) is resolved the fp64 way, by the
- *                         largest 1 / (1 + c), c = the row's mass on the other L - 1 columns; L = 0:
- *                         plain weights, fp32 arg-max only.  dist2_dev is not touched.
+ *                         ties (np.argmax).  With L > 0 the rows of phi_dev are responsibilities over L
+ *                         leaves that sum to 1: among the frames the column dominates (fp32 phi >= 0.5)
+ *                         the arg-max is taken the fp64 way, over 1 / (1 + c), c = the row's mass on the
+ *                         other L - 1 columns -- frames that tie in fp32 (all those at 1.0, or two at
+ *                         0.99976906) are ordered as the reference's fp64 phi orders them; below 0.5 and
+ *                         with L = 0 (plain weights, or rows that do not sum to 1): fp32 arg-max.
+ *                         dist2_dev is not touched.
  *   centres_dev != NULL : float [J][padded D], column j's newest centre (e.g. gathered rows of Z).
  *                         dist2_dev [N][J] is the running min squared distance (overwritten when
  *                         first != 0); score = w * sqrt(dist2).

@@ -205,3 +205,110 @@ def test_one_pass_kernel_bit_reproducible_and_full_size():
             assert torch.equal(dev.phi, first)
             assert float(((dev.estats - est0).abs() / (est0.abs() + 1.0)).max()) < 1e-12
     dev.close()
+
+
+def _clustered_latents(N, D, ncomp, seed, ep, spread, noise):
+    """Equal-mass tight clusters, fresh noise and a slow drift per epoch (legacy RandomState streams)."""
+    rng = np.random.RandomState(seed)
+    mu = rng.normal(scale=spread, size=(ncomp, D))
+    comp = rng.permutation(N) % ncomp
+    eps = np.random.RandomState(seed + 1000 + ep).normal(size=(N, D)) * noise
+    return (mu[comp] * (1.0 + 0.02 * ep) + eps).astype(np.float32)
+
+
+def test_trajectory_through_every_kernel_regime_against_oracle():
+    """BASELINE config 5's shape (D = 128, num_splits = 4, splits and prunes in every call) on a tree that
+    STARTS large: 4-ary x 5 levels (K = 1365, L = 1024).  Under the reference's own gates (a leaf splits only
+    with mean(phi) >= 1e-2 and is pruned below 1e-3, src/var_inf.py:194,217) such a tree sheds leaves call by
+    call -- 1024 -> 562 -> 297 -> 156 -> 94 -> 66 -> ... -- so one trajectory walks the E-step from the streamed
+    regime (more than 256 leaves at D = 128) through the one-pass row kernel (101 .. 256), the two-pass row
+    kernel with in-kernel S2 (65 .. 100) to the fused kernel (<= 64), the M-step from the workgroup-wide tiles
+    (padded L >= 512) to the per-wave DMA ring, with bnpvi_remap_columns / bnpvi_gamma_remap between any two of
+    them.  Compared with OracleVarInf after EVERY call: same tree (ids, parents, leaf flags), node parameters,
+    gamma, phi.  (N is chosen so that neither gate, 1e-2 N = 64.5 and 1e-3 N = 6.45 frames, sits on the
+    near-integer masses tight clusters produce.)"""
+    N, D, ncomp, seed = 6450, 128, 800, 7
+    fpv = [300, 177, 256, 640, 411, 160, 512, 616, 3378]
+    kw = dict(latent_code_size=D, stdev_thr=-100.0, num_splits=4, branching=4, levels=5)
+    ora = OracleVarInf(**kw)
+    vi = make_vi(**kw)
+    seen_L = []
+    for ep in range(7):
+        Z = _clustered_latents(N, D, ncomp, seed, ep, 3.0, 0.3)
+        lc = make_latent_dict(Z, fpv)
+        np.random.seed(13 + ep)
+        ora.update_variational_parameters(lc)
+        np.random.seed(13 + ep)
+        vi.update_variational_parameters(lc)
+        want, got = snapshot(ora), snapshot(vi)
+        assert list(got['ids']) == list(want['ids']), "tree differs after call %d" % ep
+        np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
+        np.testing.assert_array_equal(got['parent'], want['parent'])
+        close_params(got['alpha'], want['alpha'], 'alpha, call %d' % ep)
+        close_params(got['sigma'], want['sigma'], 'sigma, call %d' % ep)
+        np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=1e-4, atol=1e-3, equal_nan=True)
+        np.testing.assert_allclose(got['phi'], want['phi'], rtol=0, atol=2e-4)
+        assert float(got['decay']) == float(want['decay'])
+        seen_L.append(int(want['is_leaf'].sum()))
+    # the walk really crossed the regimes
+    assert seen_L[0] > 512 and any(256 < l <= 512 for l in seen_L) and any(100 < l <= 256 for l in seen_L)
+    assert any(64 < l <= 100 for l in seen_L) and min(seen_L) <= 64, seen_L
+
+
+def test_node_that_loses_all_children_becomes_a_leaf_with_its_stale_phi():
+    """src/var_inf.py:200-201: a node whose children are all pruned turns into a leaf and keeps the phi it had
+    when it was split.  Because removing a child while the parent iterates skips the next sibling (:196-199), the
+    branch is reachable only with num_splits = 1 -- and then only when the single child falls below the prune
+    floor, which the model's own dynamics did not produce in any fixture tried; so the state is set up through
+    the public methods: split every gated leaf into its one child, give some of those children (a caller-side
+    Node.phi assignment) a vanishing mass, merge.  Same tree as the oracle, the revived leaves carry the phi
+    they had as leaves, and that phi feeds the next M-step on the device."""
+    N, D = 3000, 8
+    fpv = [700, 400, 1900]
+    rng = np.random.RandomState(100)
+    mu = np.random.RandomState(5).normal(scale=3.0, size=(6, D))
+    Z32 = (mu[rng.randint(0, 6, size=N)] + rng.normal(size=(N, D))).astype(np.float32)
+    lc = make_latent_dict(Z32, fpv)
+    kw = dict(latent_code_size=D, stdev_thr=1e9, num_splits=1, branching=3, levels=2)
+    ora = OracleVarInf(**kw)
+    vi = make_vi(**kw)
+    np.random.seed(21)
+    ora.update_variational_parameters(lc)
+    np.random.seed(21)
+    vi.update_variational_parameters(lc)
+    Z = ora.get_matrix_from_dict(lc)
+    np.random.seed(22)
+    assert ora.split_nodes(ora.root, Z, -1.0)
+    np.random.seed(22)
+    assert vi.split_nodes(vi.root, Z, -1.0)
+    so, sp = snapshot(ora), snapshot(vi)
+    assert list(sp['ids']) == list(so['ids'])
+    # every second freshly created child loses its mass
+    def fresh_children(v):
+        return [n for n in v.get_nodes_list(v.root, []) if n.isLeafNode and n.parent is not None
+                and len(n.parent.children) == 1]
+    co, cp = fresh_children(ora), fresh_children(vi)
+    assert len(co) == len(cp) >= 2 and [n.node_id for n in co] == [n.node_id for n in cp]
+    stale = {}
+    for k, (a, b) in enumerate(zip(co, cp)):
+        if k % 2 == 0:
+            stale[a.parent.node_id] = np.array(a.parent.phi, dtype=np.float64).copy()
+            a.phi = np.full((N, 1), 1e-9)
+            b.phi = np.full((N, 1), 1e-9)
+    ora.merge_nodes(ora.root, Z, 0.0)
+    vi.merge_nodes(vi.root, Z, 0.0)
+    assert getattr(ora, 'revived_leaves', 0) == len(stale)
+    so, sp = snapshot(ora), snapshot(vi)
+    assert list(sp['ids']) == list(so['ids'])
+    np.testing.assert_array_equal(sp['is_leaf'], so['is_leaf'])
+    np.testing.assert_allclose(sp['phi'], so['phi'], rtol=0, atol=2e-4)
+    by_id = {n.node_id: n for n in vi.get_nodes_list(vi.root, [])}
+    for nid, col in stale.items():
+        assert by_id[nid].isLeafNode and not by_id[nid].children
+        np.testing.assert_allclose(np.asarray(by_id[nid].phi), col, rtol=0, atol=2e-4)
+    # the stale columns are what the next M-step sums
+    ora.compute_sigma_alpha(Z)
+    vi.compute_sigma_alpha(Z)
+    so, sp = snapshot(ora), snapshot(vi)
+    close_params(sp['alpha'], so['alpha'], 'alpha after the M-step on revived leaves')
+    close_params(sp['sigma'], so['sigma'], 'sigma after the M-step on revived leaves')
