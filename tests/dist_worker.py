@@ -5,13 +5,64 @@ of the one-process-per-GPU RCCL layout (bnp_vae_amd/dist.py).  The rank takes it
 dist.shard_videos, runs the golden trajectory through VarInf(group=...) and writes what it
 holds after every epoch.
 
-  python tests/dist_worker.py RANK WORLD PORT OUTDIR GOLDEN [config5]
+  python tests/dist_worker.py RANK WORLD PORT OUTDIR GOLDEN
+  python tests/dist_worker.py RANK WORLD PORT OUTDIR synth:N:D:COMPS:CALLS:BF:LEVELS
+      full-size synthetic run (test_gpu_round3.py): the rank's share of N clustered frames, built on the
+      device from a formula of the GLOBAL row index (the same data whatever the sharding); writes the tree ids
+      per call and a few size-independent checks instead of the matrices.
 """
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+FPV_SYNTH = 256
+
+
+def synth(rank, world, out_dir, spec, group):
+    import numpy as np
+    import torch
+    from bnp_vae_amd import VarInf
+    from bnp_vae_amd import dist as vdist
+    N, D, comps, calls, bf, levels = [int(x) for x in spec.split(":")[1:]]
+    dev = torch.device("cuda", 0)
+    V = (N + FPV_SYNTH - 1) // FPV_SYNTH
+    fpv = [min(FPV_SYNTH, N - v * FPV_SYNTH) for v in range(V)]
+    v0, v1, f0, f1 = vdist.shard_videos(fpv, world)[rank]
+    mu = torch.from_numpy(np.random.RandomState(7).normal(scale=3.0, size=(comps, D)).astype(np.float32)).to(dev)
+    keys = [(n // FPV_SYNTH, n % FPV_SYNTH) for n in range(f0, f1)]
+    np.random.seed(1000 + rank)
+    vi = VarInf(latent_code_size=D, stdev_thr=-100.0, num_splits=4, branching=bf, levels=levels, group=group)
+    out = {"f0": f0, "f1": f1, "K0": 0}
+    for call in range(calls):
+        g = torch.Generator(device=dev)
+        g.manual_seed(100 + call)
+        noise = torch.randn((N, D), generator=g, device=dev)[f0:f1]        # global stream, this rank's rows
+        rows = torch.arange(f0, f1, device=dev)
+        Z = mu[(rows * 7919) % comps] * (1.0 + 0.01 * call) + 0.3 * noise
+        del noise
+        if rank == 0:
+            np.random.seed(13 + call)
+        vi.update_variational_parameters_matrix(Z, keys=keys if call == 0 else None)
+        nodes = vi.get_nodes_list(vi.root, [])
+        out["c%d_ids" % call] = np.asarray([n.node_id for n in nodes])
+        out["c%d_is_leaf" % call] = np.asarray([bool(n.isLeafNode) for n in nodes])
+        out["c%d_alpha" % call] = np.asarray([np.asarray(n.alpha) for n in nodes])
+        # size-independent properties of a fresh E-step on the tree this call left behind
+        vi.compute_sigma_alpha(Z)
+        vi.compute_gamma()
+        vi.compute_phi(Z)
+        d = vi._dev
+        L = d.tree.L
+        rowsum = d.phi[:, :L].sum(dim=1)
+        out["c%d_rowerr" % call] = float((rowsum - 1).abs().max()) if d.N else 0.0
+        out["c%d_S0sum" % call] = float(d.estats[:, 0].sum())              # all-reduced: the global frame count
+        out["c%d_colerr" % call] = float(((d.phi[:, :L].double().sum(dim=0) - 0) .sum() - d.N).abs())
+        out["c%d_K" % call] = len(nodes)
+        torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
 
 
 def main():
@@ -27,6 +78,10 @@ def main():
     from bnp_vae_amd import VarInf
     from bnp_vae_amd import dist as vdist
     from oracle.vi_oracle import snapshot, drifting_latents
+    if golden.startswith("synth:"):
+        synth(rank, world, out_dir, golden, dist.group.WORLD if world > 1 else None)
+        dist.destroy_process_group()
+        return
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", golden), allow_pickle=False))
     m = json.loads(str(g["meta"]))
     fpv = [int(x) for x in g["fpv"]]

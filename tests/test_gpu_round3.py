@@ -312,3 +312,46 @@ def test_node_that_loses_all_children_becomes_a_leaf_with_its_stale_phi():
     so, sp = snapshot(ora), snapshot(vi)
     close_params(sp['alpha'], so['alpha'], 'alpha after the M-step on revived leaves')
     close_params(sp['sigma'], so['sigma'], 'sigma after the M-step on revived leaves')
+
+
+def _run_workers(world, spec, tmp_path, timeout=900):
+    import socket
+    import subprocess
+    import sys
+    import os
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = str(s.getsockname()[1])
+    s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / ("w%d" % world)
+    out.mkdir()
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "dist_worker.py"), str(r), str(world),
+                               port, str(out), spec], cwd=root) for r in range(world)]
+    codes = [p.wait(timeout=timeout) for p in procs]
+    assert codes == [0] * world, codes
+    return [dict(np.load(str(out / ("rank%d.npz" % r)), allow_pickle=False)) for r in range(world)]
+
+
+def test_full_size_dynamic_run_from_a_thousand_node_tree(tmp_path):
+    """BASELINE config 5 at its full size (2M frames, D = 128, num_splits = 4) on a tree that starts at K = 1365
+    nodes / 1024 leaves: three drop-in calls (device tensor in), each splitting and pruning.  Size-independent
+    properties after every call -- softmax rows, total mass = the global frame count -- and the SAME tree and
+    node parameters when the frames are sharded over two ranks (fresh processes, gloo rehearsal on this GPU) as
+    on one: the all-reduced statistics drive every structural decision."""
+    N = 2_000_128
+    spec = "synth:%d:128:777:3:4:5" % N
+    one = _run_workers(1, spec, tmp_path)[0]
+    two = _run_workers(2, spec, tmp_path)
+    ks = [int(one["c%d_K" % c]) for c in range(3)]
+    assert ks[0] >= 500 and len(set(ks)) > 1, ks                 # a large tree that keeps changing
+    for c in range(3):
+        assert float(one["c%d_rowerr" % c]) < 1e-5
+        assert abs(float(one["c%d_S0sum" % c]) - N) < 1e-6 * N
+        for r in (0, 1):
+            assert list(two[r]["c%d_ids" % c]) == list(one["c%d_ids" % c]), "call %d: tree differs on rank %d" % (c, r)
+            np.testing.assert_array_equal(two[r]["c%d_is_leaf" % c], one["c%d_is_leaf" % c])
+            close_params(two[r]["c%d_alpha" % c], one["c%d_alpha" % c], "alpha call %d rank %d" % (c, r))
+            assert float(two[r]["c%d_rowerr" % c]) < 1e-5
+            assert abs(float(two[r]["c%d_S0sum" % c]) - N) < 1e-6 * N
+    assert int(two[0]["f1"]) == int(two[1]["f0"]) and int(two[1]["f1"]) == N
