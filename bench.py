@@ -41,6 +41,7 @@ CONFIGS = {
 }
 FRAMES_PER_VIDEO = 256
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 / f16 MFMA
 
 
 def regular_tree(bf, levels):
@@ -289,17 +290,35 @@ class Runner(object):
                     traffic_at = rec["N"]
             except Exception:
                 traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": "profiles/pmc_traffic.json (rocprofv3 PMC passes of an earlier run, scaled "
+                                  "linearly in the frame count; not measured in this run)" if traffic else None,
+                "traffic_measured_at_N": traffic_at,
+                "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_ms": dom_ms,
+                "estep_ms": e_ms, "mstep_stats_ms": m_ms,
+                "iteration_frac": N * 8.0 * (D + L) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if L * D >= 256 * 1024:
+            # large trees (config 4): both data passes are matrix-pipe problems.  Algorithmic flops per launch =
+            # the one dense contraction of the kernel, 2 L D per frame (E: z . alpha^T, M: R^T Z); the kernels
+            # issue 3 (E, f16 hi/lo split) resp. 6 (M, bf16 x 3 split) products per algorithmic one to keep fp32
+            # accuracy.  Peak: dense bf16 / f16 MFMA, MI355X_MICROARCH.md.  (The E-step timer covers the logits
+            # kernel -- pass A -- of the streamed regime only.)
+            flops = 2.0 * N * L * D
+            issued = {"estep": 3.0, "mstep_stats": 6.0}[dom]
+            roof.update({"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (dom_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": flops, "issued_products_per_algorithmic": issued,
+                         "issued_frac": issued * flops / (dom_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                         "hbm_frac": achieved / HBM_PEAK_GBS,
+                         "estep_issued_tflops": 3.0 * flops / (e_ms * 1e-3) / 1e12,
+                         "mstep_issued_tflops": 6.0 * flops / (m_ms * 1e-3) / 1e12})
         return {
             "N": N, "D": D, "bf": bf, "K": K, "L": L, "V": V, "ms_per_step": ms_per_step,
             "value": N * self.world / (elapsed / steps),
             "allreduce_bytes_per_step": (L * (1 + D) * 8 + (L * 2 * 8 if want_estats else 0)) if self.world > 1 else 0,
             "ranks_seen": int(self.dist.get_world_size()) if self.world > 1 else 1,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_measured_at_N": traffic_at,
-                         "algorithmic_bytes_per_launch": kern_bytes, "avg_launch_ms": dom_ms,
-                         "estep_ms": e_ms, "mstep_stats_ms": m_ms,
-                         "iteration_frac": N * 8.0 * (D + L) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "roofline": roof,
         }
 
 
