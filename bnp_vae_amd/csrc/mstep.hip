@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
   }
 
   float s0[TL], msum[TL];
+  S0Check s0chk[TL];
 #pragma unroll
   for (int a = 0; a < TL; ++a) s0[a] = msum[a] = 0.f;
   int my_vid = -1;
@@ -178,6 +179,7 @@ __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
         const float t = ((r.a[a][0] + r.a[a][1]) + (r.a[a][2] + r.a[a][3])) +
                         ((r.a[a][4] + r.a[a][5]) + (r.a[a][6] + r.a[a][7]));
         s0_accumulate(s0[a], t);
+        s0chk[a].add(t);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -256,6 +258,7 @@ __global__ __launch_bounds__(kStatWaves * 64, 2) void leaf_stats_kernel(
       if (lead_dim) {
 #pragma unroll
         for (int a = 0; a < TL; ++a) {
+          s0chk[a].verify(s0[a], "leaf_stats", a);
           float t = s0[a] + __shfl_xor(s0[a], 32);
           if (h == 0) {
             double* dst = &s0_lds[a * 32 + i];

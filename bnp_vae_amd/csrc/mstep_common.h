@@ -122,18 +122,51 @@ __device__ __forceinline__ void mac1(int k, const Frag& ah, const Frag& am, cons
 // loop's full mask; (3) a clobbered operand -- the boundary path writes v82-85, v89-95 only.  What
 // differs is only the instruction quoted above: a packed fp32 add with op_sel whose source is the
 // result of the packed add two instructions earlier, issued as the first VALU instruction after a
-// taken branch.  Packed fp32 instructions execute in four 16-lane passes; lanes 16-31 are the second
-// pass, so the data points at that second pass reading v[2:3] before the producer's second pass had
-// written it -- a forwarding / dependency-check hazard of this instruction pair that the compiler
-// does not pad (no s_nop is emitted there), not a logic error.  It is not proven beyond the A/B
-// count; the code below does not depend on the answer:
+// taken branch.  HYPOTHESIS (round 2, never proven): a forwarding / dependency-check hazard of that
+// instruction pair that the compiler does not pad.  Round 3 looked again and found NO support for it:
+//   * LLVM's hazard tables for gfx940/950 know no such case (the dst-sel forwarding hazard concerns
+//     producers that write a half register -- SDWA dst_sel / VOP3 op_sel[3] -- which v_pk_add_f32
+//     does not), and no wait state is required between dependent VALU instructions otherwise;
+//   * the present source built with -DBNPVI_NO_S0_PIN shows the very same pair at the join
+//     (tools/isa_hazard_scan.py, profiles/r03_isa_hazard_scan.txt) and returned an exact S0 in
+//     320 000 of 320 000 launches on two MI355X boxes (tools/dev/s0_ab.py: configs 1, 2, 3), where
+//     round 2's rate would have given ~380 failures.
+// So the cause of round 2's losses is UNKNOWN (that build differed in more than this pair, and it
+// ran on other boxes).  The code below does not depend on the answer:
 //   * S0 is updated by ONE scalar-width v_add_f32 per leaf tile, written as inline asm, so it can be
 //     neither packed, nor given op_sel, nor moved across the branch;
 //   * it sits in straight-line code in front of the boundary path, behind the (also pinned) tree sum.
 // tests/test_gpu_round2.py::test_s0_is_exact_on_one_hot_responsibilities checks S0 bit for bit.
 __device__ __forceinline__ void s0_accumulate(float& s0, float t) {
+#ifdef BNPVI_NO_S0_PIN  // development only: the plain form, for tools/isa_hazard_scan.py to look at
+  s0 += t;
+#else
   asm volatile("v_add_f32 %0, %0, %1" : "+v"(s0) : "v"(t));
+#endif
 }
+
+// Debug builds only (-DBNPVI_S0_CROSSCHECK, `make variant NAME=s0chk DEFS=-DBNPVI_S0_CROSSCHECK SRCS="mstep
+// mstep_dma mstep_wide"`): every lane carries a second S0 in fp64 -- double adds are never packed and take
+// no op_sel -- and compares it with the fp32 sum when the kernel's frame loop ends.  fp32 accumulation
+// differs from it by ~1e-7 * sqrt(k-steps) relative; a lost k-step by ~1 / k-steps.  A mismatch is
+// printed (kernel, workgroup, lane, both sums), so ONE run of any test or benchmark against the debug
+// library shows a regression of the S0 path whatever the data.
+struct S0Check {
+#ifdef BNPVI_S0_CROSSCHECK
+  double sum = 0.0;
+  __device__ __forceinline__ void add(float t) { sum += (double)t; }
+  __device__ __forceinline__ void verify(float s0, const char* kernel, int a) const {
+    const double tol = 1e-4 * (sum < 0 ? -sum : sum) + 1e-6;
+    const double d = (double)s0 - sum;
+    if (d > tol || -d > tol)
+      printf("bnpvi S0 cross-check FAILED: %s wg (%d,%d) thread %d tile %d: fp32 %.9g fp64 %.9g\n", kernel,
+             (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x, a, (double)s0, sum);
+  }
+#else
+  __device__ __forceinline__ void add(float) {}
+  __device__ __forceinline__ void verify(float, const char*, int) const {}
+#endif
+};
 
 // ---- LDS-DMA helpers (mstep_dma.hip, mstep_wide.hip)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
   };
 
   float s0[TL], msum[TL];
+  S0Check s0chk[TL];
   int lcol[TL];
 #pragma unroll
   for (int a = 0; a < TL; ++a) {
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
       for (int a = 0; a < TL; ++a) {
         t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
         s0_accumulate(s0[a], t[a]);            // mstep_common.h: why this is not `s0[a] += t[a]`
+        s0chk[a].add(t[a]);
       }
       if (__builtin_expect(same_video, 1)) {
 #pragma unroll
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(kDmaWaves * 64, 1) void leaf_stats_dma_kernel(
     }
   }
   if (do_mass) flush_mass();
+  if (lead_dim)
+#pragma unroll
+    for (int a = 0; a < TL; ++a) s0chk[a].verify(s0[a], "leaf_stats_dma", a);
 
   // ---- combine the workgroup's waves in fp64 (wave order fixed => deterministic); the ring
   //      memory is free now

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float s0[TS], msum[TS];
+  S0Check s0chk[TS];
   int lcol[TS];
 #pragma unroll
   for (int a = 0; a < TS; ++a) {
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     for (int a = 0; a < TS; ++a) {
       t[a] = ((xa[a][0] + xa[a][1]) + (xa[a][2] + xa[a][3])) + ((xa[a][4] + xa[a][5]) + (xa[a][6] + xa[a][7]));
       s0_accumulate(s0[a], t[a]);            // mstep_common.h: why this is not `s0[a] += t[a]`
+      s0chk[a].add(t[a]);
     }
     if (__builtin_expect(same_video, 1)) {
 #pragma unroll
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   if (lead) {
 #pragma unroll
     for (int a = 0; a < TS; ++a) {
+      s0chk[a].verify(s0[a], "leaf_stats_wide", a);
       const float t = s0[a] + __shfl_xor(s0[a], 32);
       if (h == 0 && lcol[a] < L) out[(int64_t)lcol[a] * W] = (double)t;
     }

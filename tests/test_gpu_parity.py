@@ -54,8 +54,17 @@ def check_gated_s2(S0, S2, want_S2, N):
 
 
 def close_params(got, want, what):
+    """MAX-RELATIVE closeness: every element within PARAM_RTOL of the array's LARGEST magnitude (atol =
+    1e-4 * max|want|), not of its own.  That is the right yardstick for alpha, whose entries straddle zero
+    (an fp32 sum of O(1) terms cannot hold an entry of 1e-6 to four digits); sigma, which is >= 1 everywhere,
+    is additionally held to 1e-4 of each element by close_sigma."""
     scale = max(1.0, float(np.max(np.abs(want))))
     np.testing.assert_allclose(got, want, rtol=PARAM_RTOL, atol=PARAM_RTOL * scale, err_msg=what)
+
+
+def close_sigma(got, want, what):
+    """elementwise relative 1e-4, no absolute slack (sigmasqr_inv >= 1: src/var_inf.py:282-297)"""
+    np.testing.assert_allclose(got, want, rtol=PARAM_RTOL, atol=0.0, err_msg=what)
 
 
 def assert_snap_close(got, want, phi_atol=PHI_ATOL):
@@ -63,7 +72,7 @@ def assert_snap_close(got, want, phi_atol=PHI_ATOL):
     np.testing.assert_array_equal(got['parent'], want['parent'])
     np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
     close_params(got['alpha'], want['alpha'], 'alpha')
-    close_params(got['sigma'], want['sigma'], 'sigma')
+    close_sigma(got['sigma'], want['sigma'], 'sigma')
     np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=PARAM_RTOL, atol=1e-3, equal_nan=True)
     np.testing.assert_allclose(got['phi'], want['phi'], rtol=0, atol=phi_atol)
 
@@ -109,7 +118,7 @@ def test_phases_against_golden(name):
     vi.compute_sigma_alpha(Z)                                    # M-step
     s = snapshot(vi)
     close_params(s['alpha'], g['m_alpha'], 'alpha after M-step')
-    close_params(s['sigma'], g['m_sigma'], 'sigma after M-step')
+    close_sigma(s['sigma'], g['m_sigma'], 'sigma after M-step')
 
     vi.compute_gamma()                                           # gamma-step
     np.testing.assert_allclose(snapshot(vi)['gamma'], g['g_gamma'], rtol=PARAM_RTOL, atol=1e-4,
@@ -215,7 +224,7 @@ def test_iteration_against_oracle(N, D, bf, levels, fpv):
         ora.compute_sigma_alpha(Z); vi.compute_sigma_alpha(Z)
         so, sp = snapshot(ora), snapshot(vi)
         close_params(sp['alpha'], so['alpha'], 'alpha it%d' % it)
-        close_params(sp['sigma'], so['sigma'], 'sigma it%d' % it)
+        close_sigma(sp['sigma'], so['sigma'], 'sigma it%d' % it)
         ora.compute_gamma(); vi.compute_gamma()
         np.testing.assert_allclose(snapshot(vi)['gamma'], snapshot(ora)['gamma'], rtol=1e-4, atol=1e-4)
         ora.compute_phi(Z)
@@ -456,7 +465,15 @@ def test_class_vote_against_oracle(decay):
     p2c, pred = class_vote(nodes, z_train, labels, z_test, decay_factor=decay)
     want_p2c, want_pred = oracle_vote(vi.root, z_train.astype(np.float64), labels, z_test.astype(np.float64), decay)
     np.testing.assert_array_equal(p2c, want_p2c)
-    assert (pred != want_pred).mean() <= 0.01                           # nearest-leaf near-ties only
+    # a prediction may differ only where the frame's two nearest leaves are an fp32 near-tie: the class
+    # the product chose must belong to a leaf no further than 1e-5 (relative) beyond the nearest one
+    from oracle.hierarchy_oracle import dfs_leaves
+    alpha = np.asarray([l.alpha for l in dfs_leaves(vi.root)], dtype=np.float64)
+    for i in np.nonzero(pred != want_pred)[0]:
+        d = np.linalg.norm(alpha - z_test[i].astype(np.float64), axis=1)
+        tied = d - d.min() <= 1e-5 * max(1.0, d.min())
+        assert pred[i] in set(p2c[tied]), (i, d.min(), np.sort(d)[:3])
+    assert (pred != want_pred).mean() <= 0.01
 
 
 @pytest.mark.parametrize("cfg,N", [("config2", 262_144), ("config3", 65_536)])
@@ -551,6 +568,24 @@ def test_path_prior_branch_of_get_true_path_mean():
     # rounding of a cumulative-probability boundary
     same = np.asarray(vi.last_path_indices) == np.asarray(ora.last_path_indices)
     assert same.mean() >= 0.95
+    # ... and every differing draw IS such a boundary case: np.random.choice draws one uniform variate per
+    # call and takes cdf.searchsorted(u, 'right'); replay the variates and look at the boundaries between
+    # the two picks in the oracle's fp64 cdf
+    np.random.seed(99)
+    us = [np.random.random_sample() for _ in batch]
+    bfs, queue = [], [ora.root]
+    while queue:
+        n, queue = queue[0], queue[1:]
+        if n.isLeafNode:
+            bfs.append(n)
+        else:
+            queue = queue + n.children
+    for b in np.nonzero(~same)[0]:
+        idx = ora.vidid_frameid_to_idx.index(batch[b])
+        p = np.asarray([leaf.phi[idx][0] for leaf in bfs], dtype=np.float64)
+        cdf = np.cumsum(p / p.sum())
+        lo, hi = sorted((vi.last_path_indices[b], ora.last_path_indices[b]))
+        assert np.all(np.abs(cdf[lo:hi] - us[b]) < 1e-5), (b, us[b], cdf[lo:hi])
     np.testing.assert_allclose(got[same], want[same], rtol=PARAM_RTOL, atol=1e-6)
     assert got.shape == (64, m['D']) and len(set(vi.last_path_indices)) > 1
     plain = make_vi(latent_code_size=m['D'])

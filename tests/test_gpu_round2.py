@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from oracle.vi_oracle import (OracleVarInf, snapshot, make_latent_dict, drifting_latents, tree_from_arrays)
-from tests.test_gpu_parity import (load, sub, meta, make_vi, close_params, oracle_from_snapshot, _regular_case,
+from tests.test_gpu_parity import (load, sub, meta, make_vi, close_params, close_sigma, oracle_from_snapshot, _regular_case,
                                    PARAM_RTOL, PHI_ATOL, LOGP_ATOL)
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +37,7 @@ def test_config5_shape_trajectory_against_golden():
         np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
         np.testing.assert_array_equal(got['parent'], want['parent'])
         close_params(got['alpha'], want['alpha'], 'alpha, epoch %d' % ep)
-        close_params(got['sigma'], want['sigma'], 'sigma, epoch %d' % ep)
+        close_sigma(got['sigma'], want['sigma'], 'sigma, epoch %d' % ep)
         np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=PARAM_RTOL, atol=1e-3, equal_nan=True)
         np.testing.assert_allclose(got['phi'].sum(axis=0), want['phi_colsum'], rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(got['phi'][:: max(1, N // 64)], want['phi_rows'], rtol=0, atol=2e-4)
@@ -282,7 +282,7 @@ def test_multi_rank_trajectory_matches_single_rank_golden(golden, world, tmp_pat
             assert list(have['ids']) == list(want['ids']), "rank %d epoch %d: tree differs" % (r, ep)
             np.testing.assert_array_equal(have['is_leaf'], want['is_leaf'])
             close_params(have['alpha'], want['alpha'], 'alpha rank %d epoch %d' % (r, ep))
-            close_params(have['sigma'], want['sigma'], 'sigma rank %d epoch %d' % (r, ep))
+            close_sigma(have['sigma'], want['sigma'], 'sigma rank %d epoch %d' % (r, ep))
             assert float(have['decay']) == float(want['decay'])
             np.testing.assert_allclose(have['gamma'], want['gamma'][:, v0:v1], rtol=PARAM_RTOL, atol=1e-3, equal_nan=True)
             if 'phi' in want:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle.vi_oracle import OracleVarInf, snapshot, make_latent_dict
-from tests.test_gpu_parity import (make_vi, close_params, _regular_case, PHI_ATOL, check_gated_s2)
+from tests.test_gpu_parity import (make_vi, close_params, close_sigma, _regular_case, PHI_ATOL, check_gated_s2)
 
 pytestmark = pytest.mark.gpu
 
@@ -245,7 +245,7 @@ def test_trajectory_through_every_kernel_regime_against_oracle():
         np.testing.assert_array_equal(got['is_leaf'], want['is_leaf'])
         np.testing.assert_array_equal(got['parent'], want['parent'])
         close_params(got['alpha'], want['alpha'], 'alpha, call %d' % ep)
-        close_params(got['sigma'], want['sigma'], 'sigma, call %d' % ep)
+        close_sigma(got['sigma'], want['sigma'], 'sigma, call %d' % ep)
         np.testing.assert_allclose(got['gamma'], want['gamma'], rtol=1e-4, atol=1e-3, equal_nan=True)
         np.testing.assert_allclose(got['phi'], want['phi'], rtol=0, atol=2e-4)
         assert float(got['decay']) == float(want['decay'])
@@ -311,7 +311,7 @@ def test_node_that_loses_all_children_becomes_a_leaf_with_its_stale_phi():
     vi.compute_sigma_alpha(Z)
     so, sp = snapshot(ora), snapshot(vi)
     close_params(sp['alpha'], so['alpha'], 'alpha after the M-step on revived leaves')
-    close_params(sp['sigma'], so['sigma'], 'sigma after the M-step on revived leaves')
+    close_sigma(sp['sigma'], so['sigma'], 'sigma after the M-step on revived leaves')
 
 
 def _run_workers(world, spec, tmp_path, timeout=900):
