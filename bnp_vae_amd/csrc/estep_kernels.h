@@ -35,11 +35,27 @@ constexpr int kFT = 16;               // frames per wave tile
 constexpr int kLT = 16;               // leaves per MFMA tile
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
-// d^2 from the expansion carries an absolute error ~ 2e-7*(||z||^2+||a||^2); below this
-// fraction of (||z||^2+||a||^2)^2 its square root is no longer good to ~2e-5 and the distance
-// is recomputed by direct differences (rare: a frame that coincides with a leaf mean, which is
-// exactly what weighted_kmeans produces right after a split).
+// When is d^2 = ||z||^2 + ||a||^2 - 2 z.a good enough?  With s = ||z||^2 + ||a||^2 its absolute error is
+// bounded by E = 2e-7 * s: the products of the f16 hi/lo parts are exact, what is lost is (i) the operands'
+// third part (|x - hi - lo| <= 2^-22 |x| each) and the dropped lo*lo product, together <= 3 * 2^-22 * sum|z_i a_i|
+// <= 3.6e-7 * s / 2, (ii) the fp32 roundings of the accumulator chain (3 * DP/32 of them, each <= 2^-24 |z.a|)
+// and (iii) those of ||z||^2, ||a||^2 and their sum (~2^-23 * s) -- the worst cases do not coincide.  The bound
+// is checked through its consequence: tools/refine_fraction.py finds log phi within 3e-5 of the fp64 evaluation
+// of the same logits wherever phi >= 1e-6, on the bench mixtures and their noise-0.5 variants.  The
+// logit needs the UN-squared distance, whose error is E / (2 d).  It is accepted when EITHER
+//   * it is below 4e-5 absolute:  d >= 2.5e-3 * s, i.e. d^2 >= kRefineRel * s^2  (logit error <= 2e-5 at
+//     sigma_Z = 1; the parity tests hold log phi to 1e-4), OR
+//   * it is below 2^-22 * d, four units in the last place of the fp32 distance itself:  d^2 >= E / 2^-21 =
+//     kRefineLin * s.  Without this branch every ordinary pair of a widely spread data set (||z|| ~ 256, leaves
+//     ~360 apart) was "too close" by the absolute rule although neither the direct-difference path nor the fp32
+//     logit it feeds can do better than an ulp of d there: 10-15 % of ALL pairs took the exact path (round 2's
+//     8x cliff, profiles/r03_notes.md).
+// Below both bounds the distance is recomputed by direct differences (a frame that coincides with a leaf mean
+// -- exactly what weighted_kmeans produces right after a split -- or a tight cluster far from the origin).
 constexpr float kRefineRel = 6.25e-6f;
+constexpr float kRefineLin = 0.42f;
+// the bound on d^2 for s = ||z||^2 + ||a||^2; increasing in s, so the bound for the largest ||a||^2 screens a tile
+__device__ __forceinline__ float refine_threshold(float s) { return s * fminf(kRefineRel * s, kRefineLin); }
 constexpr int kScaleExp = 13;         // operands are scaled so that max |x| lies in [2^13, 2^14)
 
 // power-of-two scale that brings `amax` into [2^13, 2^14); returns the exponent k (scale = 2^k)
@@ -194,7 +210,7 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
 #endif
     }
   }
-  // d^2 in place.  Cancellation check: an entry below kRefineRel*(||z||^2+||a||^2)^2 cannot be
+  // d^2 in place.  Cancellation check: an entry below refine_threshold(||z||^2+||a||^2) cannot be
   // trusted; the common case is screened with ONE compare per lane (min d^2 against the bound
   // for the largest ||a||^2), the per-entry test runs only for waves that fail the screen.
   const float unscale = -2.f * pow2f(-kz) * lo_.inv_sa;
@@ -218,7 +234,7 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
   const float dmin = fminf(dmin2[0], dmin2[1]);
   const float snmax = zz + lo_.aamax;
   unsigned pend = 0u;
-  if (__builtin_expect(__ballot(dmin < kRefineRel * snmax * snmax) != 0ull, 0)) {
+  if (__builtin_expect(__ballot(dmin < refine_threshold(snmax)) != 0ull, 0)) {
     asm volatile("" ::: "memory");        // nothing of the rare path is speculated above the branch
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
@@ -228,7 +244,7 @@ __device__ __forceinline__ void tile_distances(const float* __restrict__ Z, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float sn = zz + aav[r];
-          if ((acc[T][r] < kRefineRel * sn * sn) && (kLT * T + 4 * kg + r < lvalid))
+          if ((acc[T][r] < refine_threshold(sn)) && (kLT * T + 4 * kg + r < lvalid))
             pend |= 1u << ((T * 4 + r) & 31);
         }
       }

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
       zz2[r >> 1][r & 1] = zr;
       un2[r >> 1][r & 1] = __shfl(unscale, 4 * kg + r);
       const float sn = zr + aamax;
-      thr2[r >> 1][r & 1] = kRefineRel * sn * sn;
+      thr2[r >> 1][r & 1] = refine_threshold(sn);
       const int64_t n = row0 + 4 * kg + r;
       okr[r] = n < N;
       prow[r] = prior + (int64_t)vid[okr[r] ? n : N - 1] * Lp + c;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(rows_waves(NCH) * 64, rows_waves(NCH) / 4) void est
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sn = zz2[r >> 1][r & 1] + aa;
-            if (d[t][r >> 1][r & 1] < kRefineRel * sn * sn && leaf < L) pend |= 1u << (t * 4 + r);
+            if (d[t][r >> 1][r & 1] < refine_threshold(sn) && leaf < L) pend |= 1u << (t * 4 + r);
           }
         }
         // as in tile_distances: one flagged pair per 16-lane row group (4 frames x 16 leaf columns)

@@ -188,13 +188,13 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
           dmin[r] = fminf(dmin[r], d[t][r]);
         }
       }
-      // cancellation screen (estep_kernels.h): an entry below kRefineRel * (||z||^2 + ||a||^2)^2 is recomputed by
+      // cancellation screen (estep_kernels.h): an entry below refine_threshold(||z||^2 + ||a||^2) is recomputed by
       // direct fp32 differences; one compare per frame against the bound for the largest ||a||^2 first
       bool sus = false;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float sn = zzr[r] + aamax;
-        sus |= dmin[r] < kRefineRel * sn * sn;
+        sus |= dmin[r] < refine_threshold(sn);
       }
       if (__builtin_expect(__ballot(sus) != 0ull, 0)) {
         asm volatile("" ::: "memory");      // nothing of the rare path is speculated above the branch
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kR1Waves * 64, 2) void estep_rows1_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float sn = zzr[r] + aa;
-            if (d[t][r] < kRefineRel * sn * sn) pend |= 1u << (t * 4 + r);
+            if (d[t][r] < refine_threshold(sn)) pend |= 1u << (t * 4 + r);
           }
         }
         // one flagged pair per 16-lane row group (4 frames x 16 leaf columns) and pass, the group's lanes

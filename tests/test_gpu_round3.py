@@ -314,6 +314,45 @@ def test_node_that_loses_all_children_becomes_a_leaf_with_its_stale_phi():
     close_sigma(sp['sigma'], so['sigma'], 'sigma after the M-step on revived leaves')
 
 
+@pytest.mark.parametrize("N,D,bf,levels", [
+    (4096, 64, 8, 2),      # L=64: fused kernel
+    (3000, 64, 8, 3),      # L=512: one-pass row kernel
+    (2000, 128, 4, 3),     # the reference tree's shape
+])
+def test_widely_spread_leaves_stay_on_the_common_path_within_fp32_resolution(N, D, bf, levels):
+    """The second branch of the E-step's distance screen (csrc/estep_kernels.h, refine_threshold): leaves 64 sqrt(D)
+    from the origin, frames near it, so every distance is ~512 and MANY leaves compete for a frame.  By the absolute
+    rule of rounds 1-2 (d < 2.5e-3 (||z||^2 + ||a||^2)) every single pair took the exact-distance path; the
+    expansion's error there is below four ulps of the distance, which is what the shipped rule accepts.  log phi
+    and phi must match the fp64 oracle to the same tolerances as everywhere else."""
+    from tests.test_gpu_parity import LOGP_ATOL
+    ora, vi, _ = _regular_case(N, D, bf, levels, [256], seed=9)
+    oleaves, pleaves = ora.leaves(), vi._dfs_leaves()
+    L = len(oleaves)
+    rng = np.random.RandomState(4)
+    centres = rng.normal(size=(L, D))
+    centres *= 64.0 * np.sqrt(D) / np.linalg.norm(centres, axis=1, keepdims=True)   # all leaves equally far out
+    Z = (2.0 * rng.normal(size=(N, D))).astype(np.float32)
+    for k, (lo_, lp) in enumerate(zip(oleaves, pleaves)):
+        lo_.alpha = centres[k].copy()
+        lp.alpha = centres[k].copy()
+    # which branch this exercises, in fp64
+    d2 = ((Z[:, None, :].astype(np.float64) - centres[None]) ** 2).sum(-1)
+    s = (Z.astype(np.float64) ** 2).sum(1)[:, None] + (centres.astype(np.float32).astype(np.float64) ** 2).sum(1)[None]
+    assert np.all(d2 < 6.25e-6 * s * s)                                  # absolute rule: all pairs flagged
+    assert not np.any(d2 < s * np.minimum(6.25e-6 * s, 0.42))            # shipped rule: none
+    ora.compute_phi(Z)
+    logphi, _ = vi.compute_phi(Z, want_logphi=True)
+    got = logphi.cpu().numpy()[:, :L]
+    want = ora.last_log_phi
+    po = snapshot(ora)['phi']
+    assert np.median((po > 1e-3).sum(1)) >= 2                            # leaves share frames
+    near = want > -80.0
+    np.testing.assert_allclose(got[near], want[near], rtol=0, atol=LOGP_ATOL)
+    np.testing.assert_allclose(got[~near], want[~near], rtol=1e-5, atol=LOGP_ATOL)
+    np.testing.assert_allclose(snapshot(vi)['phi'], po, rtol=0, atol=PHI_ATOL)
+
+
 def _run_workers(world, spec, tmp_path, timeout=900):
     import socket
     import subprocess
