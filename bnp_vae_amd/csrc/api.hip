@@ -159,6 +159,7 @@ int bnpvi_ctx_destroy(bnpvi_ctx* ctx) {
   ctx->slabs.release();
   ctx->pack.release();
   ctx->part.release();
+  ctx->zpack.release();
   ctx->red.release();
   ctx->cols.release();
   ctx->timer[0].release();

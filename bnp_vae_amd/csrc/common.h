@@ -88,6 +88,7 @@ struct bnpvi_ctx {
   bnpvi::Scratch slabs;      // partial-sum slabs (fp64)
   bnpvi::Scratch pack;       // packed leaf parameters for the E-step (fp32)
   bnpvi::Scratch part;       // per-frame softmax partials of the streamed E-step
+  bnpvi::Scratch zpack;      // frame-side operand fragments of the streamed E-step (as large as Z)
   bnpvi::Scratch red;        // arg-max partials of the k-means pass
   bnpvi::Scratch cols;       // column maps of remap_columns
   bnpvi::KernelTimer timer[2];   // BNPVI_PROF_ESTEP / BNPVI_PROF_MSTEP main kernels

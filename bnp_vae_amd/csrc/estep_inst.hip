@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include "estep_rows1.h"
+#include "estep_stream2.h"
 
 #ifndef BNPVI_DP
 #error "compile with -DBNPVI_DP=<padded latent dim>"
@@ -106,6 +107,35 @@ static int run_streamed(const EstepArgs& a) {
   if (cap < 1) cap = 1;
   if (bx > cap) bx = cap;
   dim3 grid((unsigned)bx, (unsigned)nchunk);
+  // soft mode with staged operands: frame fragments packed once per call, FT frame tiles per wave and unit
+  // (estep_stream2.h); falls back to the kernel below when the fragment image cannot be allocated
+  const char* env2 = dev_getenv("BNPVI_ESTEP_STREAM2");                 // development switch: "off"
+  if (a.mode == BNPVI_ESTEP_SOFT && staged && !(env2 && strcmp(env2, "off") == 0)) {
+    constexpr int FT = kStream2FT;
+    const size_t frag_bytes = (size_t)ntiles * (DP / 32) * 2 * 64 * sizeof(f16x8);
+    const size_t meta_off = (frag_bytes + 255) / 256 * 256;
+    if (a.ctx->zpack.ensure(meta_off + (size_t)ntiles * kFT * sizeof(float2)) == BNPVI_OK) {
+      f16x8* zpack = (f16x8*)a.ctx->zpack.ptr;
+      float2* zmeta = (float2*)((char*)a.ctx->zpack.ptr + meta_off);
+      const bool timed2 = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
+      int64_t pb = ceil_div(ntiles, (int64_t)4);
+      if (pb > (int64_t)a.ctx->num_cu * 32) pb = (int64_t)a.ctx->num_cu * 32;
+      hipLaunchKernelGGL(pack_latents_kernel<DP>, dim3((unsigned)pb), dim3(256), 0, a.stream, a.Z, a.ldz, a.N, zpack,
+                         zmeta);
+      const int64_t nunits = ceil_div(ntiles, (int64_t)FT);
+      int64_t ux = ceil_div(nunits, (int64_t)kS2Waves);
+      if (ux > cap) ux = cap;
+      auto k2 = estep_logits2_kernel<DP, NT, FT>;
+      if (lds > 48 * 1024)
+        BNPVI_HIP(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k2, dim3((unsigned)ux, (unsigned)nchunk), dim3(kS2Waves * 64), lds, a.stream, a.Z, a.ldz,
+                         a.vid, a.N, a.tree->L, Lp, zpack, zmeta, a.apack, a.aavec, a.a32, a.scal, a.prior,
+                         a.half_sz, a.phi, part, nchunk);
+      if (timed2) a.ctx->timer[BNPVI_PROF_ESTEP].end(a.stream);
+      BNPVI_LAUNCH_CHECK();
+      return estep_finish_streamed(a, part, nchunk);
+    }
+  }
   const bool timed = a.ctx->profiling && a.ctx->timer[BNPVI_PROF_ESTEP].begin(a.stream);
 #define BNPVI_LAUNCH_LOGITS(HARD_, WAVES_, LDS_)                                                           \
   do {                                                                                                    \

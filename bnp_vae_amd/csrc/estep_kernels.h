@@ -55,7 +55,12 @@ constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kRefineRel = 6.25e-6f;
 constexpr float kRefineLin = 0.42f;
 // the bound on d^2 for s = ||z||^2 + ||a||^2; increasing in s, so the bound for the largest ||a||^2 screens a tile
-__device__ __forceinline__ float refine_threshold(float s) { return s * fminf(kRefineRel * s, kRefineLin); }
+__device__ __forceinline__ float refine_threshold(float s) {
+#ifdef BNPVI_ABLATE_NOSPLIT
+  return -1.f;
+#endif
+  return s * fminf(kRefineRel * s, kRefineLin);
+}
 constexpr int kScaleExp = 13;         // operands are scaled so that max |x| lies in [2^13, 2^14)
 
 // power-of-two scale that brings `amax` into [2^13, 2^14); returns the exponent k (scale = 2^k)
@@ -68,6 +73,13 @@ __device__ __forceinline__ float pow2f(int k) { return __int_as_float((127 + k) 
 
 // exact hi/lo split of 8 scaled fp32 values into two f16x8 fragments
 __device__ __forceinline__ void split8(const float4& a, const float4& b, float s, f16x8& hi, f16x8& lo) {
+#ifdef BNPVI_ABLATE_NOSPLIT   // development only: the conversion's VALU work taken out (results are garbage)
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t ra = {a.x, a.y, a.z, a.w}, rb = {b.x * s, b.y, b.z, b.w};
+  hi = __builtin_bit_cast(f16x8, ra);
+  lo = __builtin_bit_cast(f16x8, rb);
+  return;
+#endif
   const float v[8] = {a.x * s, a.y * s, a.z * s, a.w * s, b.x * s, b.y * s, b.z * s, b.w * s};
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -766,14 +778,20 @@ __global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logi
     tile_distances<DP, NT>(Z, ldz, tile * kFT, N, zA, zB, tile + tstride < ntiles ? (tile + tstride) * kFT : -1, lo_,
                            lane, tiles_valid, L - kLT * T0, d2);
 #endif
+#ifdef BNPVI_ABLATE_A_NOPRIOR
+    const float* prow = nullptr;
+#else
     const float* prow = HARD ? nullptr : prior + (int64_t)vid[nn] * Lp + kLT * T0;
+#endif
     float m = -INFINITY;
     int best = 0x7fffffff;
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
       const bool tv = T < tiles_valid;
       float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef BNPVI_ABLATE_A_NOPRIOR
       if (!HARD && tv) p4 = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * kg);
+#endif
       const float pr[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -782,7 +800,11 @@ __global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logi
         if (HARD)
           v = leaf < L ? -d2[T][r] : -INFINITY;
         else
+#ifdef BNPVI_ABLATE_A_NOEPI
+          v = tv ? fmaf(-half_sz, d2[T][r], pr[r] * kLn2) : -INFINITY;
+#else
           v = tv ? fmaf(-half_sz, __builtin_amdgcn_sqrtf(d2[T][r]), pr[r] * kLn2) : -INFINITY;
+#endif
         d2[T][r] = v;
         if (v > m) {
           m = v;
@@ -808,11 +830,41 @@ __global__ __launch_bounds__((WAVES > 0 ? WAVES : kEWaves) * 64) void estep_logi
       for (int T = 0; T < NT; ++T)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
+#ifdef BNPVI_ABLATE_A_NOEPI
+          ssum += (m == -INFINITY) ? 0.f : (d2[T][r] - m) * kLog2e;
+#else
           ssum += (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((d2[T][r] - m) * kLog2e);
+#endif
       ssum += __shfl_xor(ssum, 16);
       ssum += __shfl_xor(ssum, 32);
       second = ssum;
     }
+#ifdef BNPVI_ABLATE_A_NOSTORE
+    if (m == -123.f)
+#endif
+#ifndef BNPVI_LOGITS_STORE_64B
+    if (tile * kFT + kFT <= N) {
+      // whole 128-byte lines per store instruction, non-temporal (the logits are next read by the normalising
+      // pass, after ~L/128 times their size has gone by): pairs of leaf tiles are traded between the two halves
+      // of the frame columns as in the fused kernel's epilogue (tiles_valid is even: Lp is a multiple of 32)
+      float* base = phi + (n - j + (j & 7)) * Lp + kLT * T0 + (j >> 3) * kLT + 4 * kg;
+#pragma unroll
+      for (int T = 0; T + 1 < NT; T += 2) {
+        if (T < tiles_valid) {
+          f32x4 va, vb;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int a = (int)__float_as_uint(d2[T][c]), b = (int)__float_as_uint(d2[T + 1][c]);
+            va[c] = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false));
+            vb[c] = __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false));
+          }
+          store_phi4(base + kLT * T, va);
+          store_phi4(base + 8 * Lp + kLT * T, vb);
+        }
+      }
+      if (kg == 0) part[n * nchunk + chunk] = make_float2(m, second);
+    } else
+#endif
     if (ok) {
       float* row = phi + n * Lp + kLT * T0;
 #pragma unroll
