@@ -301,18 +301,21 @@ class Runner(object):
         if L * D >= 256 * 1024:
             # large trees (config 4): both data passes are matrix-pipe problems.  Algorithmic flops per launch =
             # the one dense contraction of the kernel, 2 L D per frame (E: z . alpha^T, M: R^T Z); the kernels
-            # issue 3 (E, f16 hi/lo split) resp. 6 (M, bf16 x 3 split) products per algorithmic one to keep fp32
-            # accuracy.  Peak: dense bf16 / f16 MFMA, MI355X_MICROARCH.md.  (The E-step timer covers the logits
-            # kernel -- pass A -- of the streamed regime only.)
+            # issue 3 products per algorithmic one (f16 hi/lo split; the M-step's wide kernel takes that split where
+            # the padded tree has >= 1024 x 256 leaf x dim entries, else the exact bf16 x 3 split with 6) to keep
+            # fp32 accuracy.  Peak: dense bf16 / f16 MFMA, MI355X_MICROARCH.md.  (The E-step timer covers the fragment
+            # pre-pass and the logits kernel -- pass A -- of the streamed regime only.)
             flops = 2.0 * N * L * D
-            issued = {"estep": 3.0, "mstep_stats": 6.0}[dom]
+            m_issued = 3.0 if (-(-L // 32) * 32) * (256 if D > 128 else 0) >= 1024 * 256 else 6.0
+            issued = {"estep": 3.0, "mstep_stats": m_issued}[dom]
             roof.update({"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / (dom_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": flops, "issued_products_per_algorithmic": issued,
                          "issued_frac": issued * flops / (dom_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                          "hbm_frac": achieved / HBM_PEAK_GBS,
                          "estep_issued_tflops": 3.0 * flops / (e_ms * 1e-3) / 1e12,
-                         "mstep_issued_tflops": 6.0 * flops / (m_ms * 1e-3) / 1e12})
+                         "mstep_issued_products_per_algorithmic": m_issued,
+                         "mstep_issued_tflops": m_issued * flops / (m_ms * 1e-3) / 1e12})
         return {
             "N": N, "D": D, "bf": bf, "K": K, "L": L, "V": V, "ms_per_step": ms_per_step,
             "value": N * self.world / (elapsed / steps),

@@ -149,6 +149,10 @@ int bnpvi_ctx_create(int device, bnpvi_ctx** out) {
     delete c;
     return rc;
   }
+  if (hipMalloc(&c->small, 256) != hipSuccess) {      // device scalars: allocated here so that no entry point has to
+    (void)hipGetLastError();
+    c->small = nullptr;                               // (the wide M-step then keeps its exact split)
+  }
   *out = c;
   return BNPVI_OK;
 }
@@ -162,6 +166,7 @@ int bnpvi_ctx_destroy(bnpvi_ctx* ctx) {
   ctx->zpack.release();
   ctx->red.release();
   ctx->cols.release();
+  if (ctx->small) (void)hipFree(ctx->small);
   ctx->timer[0].release();
   ctx->timer[1].release();
   delete ctx;

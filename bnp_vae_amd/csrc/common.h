@@ -91,6 +91,7 @@ struct bnpvi_ctx {
   bnpvi::Scratch zpack;      // frame-side operand fragments of the streamed E-step (as large as Z)
   bnpvi::Scratch red;        // arg-max partials of the k-means pass
   bnpvi::Scratch cols;       // column maps of remap_columns
+  void* small = nullptr;     // 256 bytes of device scalars, allocated with the context (max|Z| of the wide M-step)
   bnpvi::KernelTimer timer[2];   // BNPVI_PROF_ESTEP / BNPVI_PROF_MSTEP main kernels
   bool profiling = false;
   // leaf operands packed ahead of the E-step by bnpvi_params_prior (one use)

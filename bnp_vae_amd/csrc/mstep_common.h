@@ -13,10 +13,36 @@ constexpr int kStatWaves = 4;          // waves per workgroup
 constexpr int kMaxChunk = 8192;        // frames summed in fp32 before promotion to fp64
 constexpr int kKStep = 16;             // frames per MFMA k-step
 
+typedef _Float16 f16x8m __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2m __attribute__((ext_vector_type(2)));
+typedef float f32x2m __attribute__((ext_vector_type(2)));
+
 union Frag {
   uint32_t u[4];
   bf16x8 v;
+  f16x8m vh;     // the same 16 bytes as eight f16 (two-piece split, mstep_wide.hip)
 };
+
+// ---- two-piece f16 split (mstep_wide.hip, F16 mode): x * scale = hi + lo + O(2^-22 |x * scale|)
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {            // {a (low half), b (high half)}, RNE
+  const f16x2m h = __builtin_convertvector((f32x2m){a, b}, f16x2m);
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ float f16_lo_as_float(uint32_t p) {
+  return (float)__builtin_bit_cast(f16x2m, p)[0];
+}
+__device__ __forceinline__ float f16_hi_as_float(uint32_t p) {
+  return (float)__builtin_bit_cast(f16x2m, p)[1];
+}
+__device__ __forceinline__ void split2h(const float (&x)[8], float scale, Frag& h, Frag& l) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float s0 = x[2 * q] * scale, s1 = x[2 * q + 1] * scale;
+    const uint32_t hp = pack_f16(s0, s1);
+    h.u[q] = hp;
+    l.u[q] = pack_f16(s0 - f16_lo_as_float(hp), s1 - f16_hi_as_float(hp));
+  }
+}
 
 // exact 3-way bf16 split of 8 fp32 values: x[e] = h[e] + m[e] + l[e]
 __device__ __forceinline__ void split3(const float (&x)[8], Frag& h, Frag& m, Frag& l) {
@@ -102,6 +128,19 @@ __device__ __forceinline__ void mac1(int k, const Frag& ah, const Frag& am, cons
   const Frag& a = (k == 0) ? al : (k == 2 || k == 3) ? am : ah;
   const Frag& b = (k == 0 || k == 3 || k == 5) ? bh : (k == 1) ? bl : bm;
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, acc, 0, 0, 0);
+}
+
+// three products of the two-piece f16 split (lo*hi + hi*lo + hi*hi), same order in mac1h
+__device__ __forceinline__ void mac3h(const Frag& ah, const Frag& al, const Frag& bh, const Frag& bl, f32x16& acc) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al.vh, bh.vh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.vh, bl.vh, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah.vh, bh.vh, acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mac1h(int k, const Frag& ah, const Frag& al, const Frag& bh, const Frag& bl,
+                                      f32x16& acc) {
+  const Frag& a = (k == 0) ? al : ah;
+  const Frag& b = (k == 1) ? bl : bh;
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.vh, b.vh, acc, 0, 0, 0);
 }
 
 // ---- S0 accumulation (mstep_dma.hip, mstep_wide.hip, mstep.hip)

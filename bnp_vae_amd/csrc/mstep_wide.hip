@@ -23,6 +23,7 @@
 //     MFMA on ks (operands split in the previous round) || read + convert ks+1
 // The waves of a workgroup work on the SAME frames and DIFFERENT outputs, so there is no
 // cross-wave combine: every wave writes its accumulators straight into the chunk's fp64 slab.
+#include <cstring>
 #include <type_traits>
 
 #include "mstep_common.h"
@@ -61,9 +62,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Tile t (t < TD: Z tiles, then the phi tiles) has 4 element pairs, a pair is split in three
 // stages of 4 + 4 + 3 VALU operations; stage idx = 12 t + 3 pair + st runs behind product
 // stage_pos(idx), tile t is read from LDS ~9 products ahead of its first stage.
-template <int TL, int TD>
+template <int TL, int TD, int PP = 6>     // PP: products per (leaf tile, dim tile) pair
 struct WideSched {
-  static constexpr int NT = TL + TD, NM = TL * TD * 6, NS = 12 * NT;
+  static constexpr int NT = TL + TD, NM = TL * TD * PP, NS = 12 * NT;
   static constexpr int kLead = 3;                         // products before the first stage
   static constexpr int stage_pos(int idx) { return kLead + (idx * (NM - 1 - kLead)) / (NS - 1); }
   static constexpr int first_stage_at(int g) {
@@ -104,11 +105,16 @@ __device__ __forceinline__ void wide_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int LBW, int DBW, int TL, int TD>
+// F16: the operands are split into TWO f16 pieces after a power-of-two scaling (phi by 2^14, Z by the power of
+// two that brings max|Z| -- zamax[0], found by absmax_kernel -- into [2^14, 2^15)) and THREE products are taken
+// (lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16): the E-step's arithmetic (operands good to 2^-22, the
+// lo*lo product dropped) instead of the exact bf16 x 3 split's six products.  For trees large enough that the
+// matrix pipe bounds the pass (config 4) that halves its time.
+template <int LBW, int DBW, int TL, int TD, bool F16>
 __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     const float* __restrict__ Z, int ldz, const float* __restrict__ phi, int ldphi,
     const int32_t* __restrict__ vid, int64_t N, int D, int L, int64_t chunk, double* __restrict__ slab,
-    int W, double* __restrict__ mass, int gx, int gy, int gz) {
+    int W, double* __restrict__ mass, int gx, int gy, int gz, const uint32_t* __restrict__ zamax) {
   using Slot = WideSlot<LBW, DBW, TL, TD>;
   constexpr int R = kWideRing;
   constexpr int AL = Slot::kAL, BD = Slot::kBD, PW = Slot::kPW;
@@ -132,6 +138,16 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   static_assert(TS * DBW == TL, "leaf tiles must divide over the waves of a row");
   const bool lead = (bz == 0);
   const bool do_mass = lead && (mass != nullptr);
+  constexpr int PP = F16 ? 3 : 6;
+  float sc_a = 1.f, sc_b = 1.f;                  // F16: operand scales (powers of two)
+  double unscale = 1.0;
+  if constexpr (F16) {
+    const uint32_t eb = (zamax[0] >> 23) & 0xffu;                  // exponent of max|Z|
+    const int kb = (eb == 0u || eb == 255u) ? 0 : 14 - ((int)eb - 127);
+    sc_a = 16384.f;
+    sc_b = __uint_as_float((uint32_t)(127 + (kb < -100 ? -100 : (kb > 100 ? 100 : kb))) << 23);
+    unscale = 1.0 / ((double)sc_a * (double)sc_b);
+  }
 
   const int64_t n0 = (int64_t)cx * chunk < N ? (int64_t)cx * chunk : N;
   const int64_t n1 = (n0 + chunk < N) ? n0 + chunk : N;
@@ -288,7 +304,12 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #pragma unroll
     for (int a = 0; a < TL; ++a)
 #pragma unroll
-      for (int b = 0; b < TD; ++b) mac6(o.ah[a], o.am[a], o.al[a], o.bh[b], o.bm[b], o.bl[b], acc[a][b]);
+      for (int b = 0; b < TD; ++b) {
+        if constexpr (F16)
+          mac3h(o.ah[a], o.al[a], o.bh[b], o.bl[b], acc[a][b]);
+        else
+          mac6(o.ah[a], o.am[a], o.al[a], o.bh[b], o.bm[b], o.bl[b], acc[a][b]);
+      }
   };
   // One k-step of the software pipeline: the matrix products of k-step ks (operands `cur`,
   // already split) run while the VALU splits k-step ks+1 out of LDS into `nxt`, so the two
@@ -316,7 +337,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #endif
     // Hand-placed schedule (WideSched; fences keep the compiler from bunching the matrix
     // instructions and doing the VALU work of the split afterwards).
-    using Sched = WideSched<TL, TD>;
+    using Sched = WideSched<TL, TD, PP>;
     static_assert(Sched::consistent(), "split schedule");
     constexpr int NT = Sched::NT;
     float x[NT][8];
@@ -334,6 +355,26 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
       r0 = q0 = x0;
       r1 = q1 = x1;
 #endif
+      if constexpr (F16) {
+        const float sc = t < TD ? sc_b : sc_a;
+        if (st == 0) {
+          r0 = x0 * sc;
+          r1 = x1 * sc;
+          q0 = __uint_as_float(pack_f16(r0, r1));                  // the hi pieces
+          asm volatile("" : "+v"(r0), "+v"(r1), "+v"(q0));
+        } else if (st == 1) {
+          r0 -= f16_lo_as_float(__float_as_uint(q0));
+          r1 -= f16_hi_as_float(__float_as_uint(q0));
+          asm volatile("" : "+v"(r0), "+v"(r1));
+        } else {
+          Frag& H = t < TD ? nxt.bh[t] : nxt.ah[t - TD];
+          Frag& Lo = t < TD ? nxt.bl[t] : nxt.al[t - TD];
+          H.u[q] = __float_as_uint(q0);
+          Lo.u[q] = pack_f16(r0, r1);
+          asm volatile("" : "+v"(H.u[q]), "+v"(Lo.u[q]));
+        }
+        return;
+      }
       if (st == 0) {
         r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u);
         r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
@@ -358,8 +399,11 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
     ld(0);
     static_for<Sched::NM>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
-      constexpr int a = (g / 6) / TD, b = (g / 6) % TD;
-      mac1(g % 6, cur.ah[a], cur.am[a], cur.al[a], cur.bh[b], cur.bm[b], cur.bl[b], acc[a][b]);
+      constexpr int a = (g / PP) / TD, b = (g / PP) % TD;
+      if constexpr (F16)
+        mac1h(g % PP, cur.ah[a], cur.al[a], cur.bh[b], cur.bl[b], acc[a][b]);
+      else
+        mac1(g % 6, cur.ah[a], cur.am[a], cur.al[a], cur.bh[b], cur.bm[b], cur.bl[b], acc[a][b]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (Sched::load_at(g) >= 0) ld(Sched::load_at(g));
       if constexpr (g == Sched::NM - 8) load_stat(slot1, xs, v15);
@@ -395,12 +439,18 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #pragma unroll
       for (int b = 0; b < TD; ++b) {
         load_b(ring, b, x);
-        split3(x, A.bh[b], A.bm[b], A.bl[b]);
+        if constexpr (F16)
+          split2h(x, sc_b, A.bh[b], A.bl[b]);
+        else
+          split3(x, A.bh[b], A.bm[b], A.bl[b]);
       }
 #pragma unroll
       for (int a = 0; a < TL; ++a) {
         load_a(ring, 0, a, std::true_type{}, x);
-        split3(x, A.ah[a], A.am[a], A.al[a]);
+        if constexpr (F16)
+          split2h(x, sc_a, A.ah[a], A.al[a]);
+        else
+          split3(x, A.ah[a], A.am[a], A.al[a]);
       }
       if (lead) {
         float xs[TS][8];
@@ -436,7 +486,7 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int leaf = by * AL + wl * (32 * TL) + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (leaf < L && dim < D) out[(int64_t)leaf * W + 1 + dim] = (double)acc[a][b][r];
+        if (leaf < L && dim < D) out[(int64_t)leaf * W + 1 + dim] = F16 ? (double)acc[a][b][r] * unscale : (double)acc[a][b][r];
       }
     }
   if (lead) {
@@ -449,7 +499,23 @@ __global__ __launch_bounds__(kWideWaves * 64) void leaf_stats_wide_kernel(
   }
 }
 
-template <int LBW, int DBW, int TL, int TD>
+// max |Z| as the bit pattern of a non-negative float (unsigned order = float order); out[0] zeroed by the caller
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* __restrict__ Z4, int64_t n4, uint32_t* out) {
+  float m = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = Z4[e];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+  __shared__ float wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (every wave of a large grid on ONE address serialises: 195 us at 131k frames)
+  if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+}
+
+template <int LBW, int DBW, int TL, int TD, bool F16 = false>
 static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi, const int32_t* vid,
                     int64_t N, int D, int L, int W, double* stats, double* mass, hipStream_t s) {
   using Slot = WideSlot<LBW, DBW, TL, TD>;
@@ -481,11 +547,20 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   double* slab_ws = nullptr;
   int rc = slab_workspace(ctx, (size_t)gx * L * W * sizeof(double), &slab_ws);
   if (rc) return rc;
-  auto kern = leaf_stats_wide_kernel<LBW, DBW, TL, TD>;
+  auto kern = leaf_stats_wide_kernel<LBW, DBW, TL, TD, F16>;
   BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const bool timed = ctx->profiling && ctx->timer[BNPVI_PROF_MSTEP].begin(s);
+  uint32_t* zamax = nullptr;
+  if (F16) {                                    // the scale of the Z pieces: one more read of Z (rows are ldz long, padding zero)
+    zamax = (uint32_t*)ctx->small;
+    BNPVI_HIP(hipMemsetAsync(zamax, 0, sizeof(uint32_t), s));
+    const int64_t n4 = N * ldz / 4;
+    int64_t ab = ceil_div(n4, (int64_t)256 * 8);
+    if (ab > (int64_t)ctx->num_cu * 4) ab = (int64_t)ctx->num_cu * 4;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)ab), dim3(256), 0, s, (const float4*)Z, n4, zamax);
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(kWideWaves * 64), lds, s, Z, ldz, phi, ldphi, vid, N, D, L,
-                     chunk, slab_ws, W, mass, (int)gx, gy, gz);
+                     chunk, slab_ws, W, mass, (int)gx, gy, gz, zamax);
   if (timed) ctx->timer[BNPVI_PROF_MSTEP].end(s);
   BNPVI_LAUNCH_CHECK();
   return launch_slab_reduce(slab_ws, (int)gx, (int64_t)L * W, stats, s);
@@ -501,6 +576,12 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
   // 512 x 128 at D <= 128, 512 x 64 at D <= 64.  Thresholds measured against the per-wave ring of
   // mstep_dma.hip (1M frames, kernel us, ring -> wide): D=256 L=256 993 -> 737, L=343 1637 -> 1196;
   // D=128 L=512 1040 -> 787, L=625 1606 -> 1267; D=64 L=512 (2M frames) 1113 -> 993.
+  // F16 mode (three products instead of six) where the matrix pipe bounds the pass: D padded to 256 and
+  // thousands of leaves (config 4).  Smaller trees are HBM-bound and keep the exact split.
+  const char* env = dev_getenv("BNPVI_WIDE_F16");                       // development switch: "off" / "on"
+  const bool f16 = env ? strcmp(env, "off") != 0 : ((int64_t)ldphi * ldz >= (int64_t)1024 * 256);
+  if (ldz % 256 == 0 && ldphi >= 256 && f16 && ctx->small != nullptr && (((uintptr_t)Z) & 15) == 0)
+    return run_wide<2, 2, 4, 4, true>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz % 256 == 0 && ldphi >= 256)
     return run_wide<2, 2, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz % 128 == 0 && ldphi >= 512)

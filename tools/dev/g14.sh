@@ -1,7 +1,6 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-BNPVI_LIB=bnp_vae_amd/variants/libbnpvi_knobs.so timeout -k 10 300 python -u tools/dev/stream2_check.py 2>&1 | grep -v amdgpu.ids || exit 1
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 300 --timeout-method thread > gpurun_out/g14_tests.log 2>&1
 rc=$?; tail -4 gpurun_out/g14_tests.log; [ $rc -ne 0 ] && exit $rc
 bash tools/prof_run.sh config4_4M --config config4 --steps 3 --warmup 1 || exit 1
