@@ -353,6 +353,41 @@ def test_widely_spread_leaves_stay_on_the_common_path_within_fp32_resolution(N, 
     np.testing.assert_allclose(snapshot(vi)['phi'], po, rtol=0, atol=PHI_ATOL)
 
 
+@pytest.mark.parametrize("N,D,bf,levels,zscale", [
+    (6000, 256, 6, 4, 1.0),        # L = 1296 -> padded 1312 x 256: the smallest tree on the f16 path
+    (5003, 200, 4, 5, 300.0),      # ragged N, D padded 200 -> 256, latents far from unit scale
+    (4000, 256, 6, 5, 1e-3),       # config 4's tree, tiny latents (the scale exponent goes the other way)
+])
+def test_wide_mstep_two_piece_f16_split_against_fp64(N, D, bf, levels, zscale):
+    """mstep_wide.hip, F16 mode (matrix-pipe-bound trees: padded leaves x padded dims >= 1024 x 256): operands
+    scaled by powers of two (max|Z| found by a pre-pass) and split into two f16 pieces, three products.  S1 = phi^T Z
+    against torch fp64 to 1e-6 of its largest entry (the operands are good to 2^-22; the rest is the fp32
+    accumulation every M-step kernel has), S0 and the per-video masses against the column sums."""
+    import torch
+    from bench import regular_tree, make_latents
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    parent, is_leaf = regular_tree(bf, levels)
+    K, L = len(parent), int(is_leaf.sum())
+    assert _lib.padded_leaves(L) * _lib.padded_dim(D) >= 1024 * 256
+    dev = DeviceVI(device=0)
+    Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
+    dev.set_latents(Z * zscale, vid, V)
+    dev.set_tree(parent, is_leaf, zscale * np.random.RandomState(13).normal(size=(K, D)), np.ones(K))
+    dev.default_gamma()
+    dev.estep(mode=_lib.ESTEP_HARD, want_stats=False)
+    dev.iteration(want_estats=False)                       # soft responsibilities
+    dev.leaf_stats(want_q=False, want_mass=True)
+    phi64 = dev.phi[:, :L].to(torch.float64)
+    ref = phi64.T @ dev.Z[:, :D].to(torch.float64)
+    got = dev.stats[:, 1:]
+    assert float((got - ref).abs().max() / ref.abs().max()) < 1e-6
+    np.testing.assert_allclose(dev.stats[:, 0].cpu().numpy(), phi64.sum(0).cpu().numpy(), rtol=2e-6, atol=1e-6)
+    per_video = torch.zeros((V, L), dtype=torch.float64, device=dev.device).index_add_(0, dev.vid.long(), phi64)
+    np.testing.assert_allclose(dev.mass.cpu().numpy(), per_video.cpu().numpy(), rtol=2e-6, atol=1e-6)
+    dev.close()
+
+
 def _run_workers(world, spec, tmp_path, timeout=900):
     import socket
     import subprocess
