@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void split_gate_kernel(const double* __restric
   }
 }
 
-constexpr int kS2Rows = 2048;         // frames per workgroup: fp32 partial sums stay short, >= 4 workgroups per CU at 2M frames
+constexpr int kS2Rows = 2048;         // most frames per workgroup: fp32 partial sums stay short, >= 4 workgroups per CU at 2M frames
+constexpr int kS2RowsMin = 256;       // fewest (small frame counts: enough workgroups to fill the chip)
 
 template <int G>
 __global__ __launch_bounds__(256) void leaf_s2_kernel(const float* __restrict__ Z, int ldz, int64_t N,
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(256) void leaf_s2_kernel(const float* __restrict__ 
                                                       const int32_t* __restrict__ node_of_leaf,
                                                       const int32_t* __restrict__ cols,
                                                       const int32_t* __restrict__ count,
-                                                      double* __restrict__ slab /* [workgroups][kS2Cap] */) {
+                                                      double* __restrict__ slab /* [workgroups][kS2Cap] */,
+                                                      int rows /* frames per workgroup */) {
   constexpr int Dp = 4 * G;
   constexpr int kRounds = kS2Cap / G;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(256) void leaf_s2_kernel(const float* __restrict__ 
   float acc[kRounds];
 #pragma unroll
   for (int q = 0; q < kRounds; ++q) acc[q] = 0.f;
-  const int64_t r0 = (int64_t)blockIdx.x * kS2Rows;
-  const int64_t r1 = r0 + kS2Rows < N ? r0 + kS2Rows : N;
+  const int64_t r0 = (int64_t)blockIdx.x * rows;
+  const int64_t r1 = r0 + rows < N ? r0 + rows : N;
   for (int64_t n = r0 + grp; n < r1; n += kGroups) {
     const float4 z = *reinterpret_cast<const float4*>(Z + n * ldz + 4 * g);
     const float* prow = phi + n * ldphi;
@@ -165,7 +167,11 @@ int launch_leaf_s2(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
                    int cap, double* s2, hipStream_t s) {
   const int Dp = bnpvi_padded_dim(D);
   const int G = Dp / 4;
-  const int64_t blocks = N > 0 ? ceil_div(N, (int64_t)kS2Rows) : 0;
+  // frames per workgroup: about four workgroups per CU, between kS2RowsMin and kS2Rows (a function of N and the
+  // chip only, so the summation order is reproducible)
+  int64_t rows = ceil_div(N > 0 ? N : 1, (int64_t)4 * ctx->num_cu);
+  rows = rows < kS2RowsMin ? kS2RowsMin : (rows > kS2Rows ? kS2Rows : rows);
+  const int64_t blocks = N > 0 ? ceil_div(N, rows) : 0;
   double* slab = nullptr;
   if (blocks > 0) {
     int rc = slab_workspace(ctx, (size_t)blocks * kS2Cap * sizeof(double), &slab);
@@ -178,7 +184,7 @@ int launch_leaf_s2(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
     if (lds > 48 * 1024)                                                                                      \
       BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));   \
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, Z, ldz, N, phi, ldphi, alpha, D,         \
-                       t->d_node_of_leaf, cols, count, slab);                                                 \
+                       t->d_node_of_leaf, cols, count, slab, (int)rows);                                            \
   } while (0)
     switch (G) {
       case 8: BNPVI_S2(8); break;
