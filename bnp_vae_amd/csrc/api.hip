@@ -267,6 +267,9 @@ int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_
     std::vector<int> fill(t->level_ptr.begin(), t->level_ptr.end() - 1);
     for (int k = 0; k < K; ++k) t->level_nodes[fill[t->depth[k]]++] = k;
   }
+  t->internal_levels = 0;
+  for (int k = 0; k < K; ++k)
+    if (t->leaf_of_node[k] < 0 && t->depth[k] + 1 > t->internal_levels) t->internal_levels = t->depth[k] + 1;
   BNPVI_HIP(hipSetDevice(ctx->device));
   int rc = BNPVI_OK;
   if ((rc = upload(t->parent, &t->d_parent)) || (rc = upload(t->depth, &t->d_depth)) ||

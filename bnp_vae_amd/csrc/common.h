@@ -116,6 +116,7 @@ struct bnpvi_ctx {
 struct bnpvi_tree {
   bnpvi_ctx* ctx = nullptr;
   int K = 0, L = 0, Lp = 0, nlevels = 0;
+  int internal_levels = 0;   // levels 0 .. internal_levels-1 hold at least one internal node (deeper ones only leaves)
   // host copies (pre-order node numbering, DFS leaf numbering)
   std::vector<int32_t> parent, depth, leaf_of_node, node_of_leaf, leaf_lo, leaf_hi;
   std::vector<int32_t> child_ptr, child_idx, level_ptr, level_nodes;

@@ -460,6 +460,7 @@ struct MidArgs {
   const int32_t *level_nodes, *level_ptr, *parent, *leaf_of_node, *node_of_leaf, *child_ptr, *child_idx,
       *leaf_lo, *leaf_hi;
   int nlevels, K, L, Lp;
+  int internal_levels;     // the node update's level loop starts at internal_levels - 1: deeper levels hold only leaves
   // node parameters
   const double* stats;
   int W, D;
@@ -562,7 +563,10 @@ __device__ __forceinline__ void params_operands_lds_block(const MidArgs& a, char
   __syncthreads();
 
   // ---- internal nodes, deepest level first
-  for (int lev = a.nlevels - 1; lev >= 0; --lev) {
+#ifdef BNPVI_TABLATE_B0_NOLEVELS
+  if (K < 0)
+#endif
+  for (int lev = a.internal_levels - 1; lev >= 0; --lev) {
     const int off = level_ptr[lev];
     const int count = level_ptr[lev + 1] - off;
     bool any = false;
@@ -589,30 +593,46 @@ __device__ __forceinline__ void params_operands_lds_block(const MidArgs& a, char
   // ---- leaf operands of the E-step from the LDS copy (layout: leaf_operands_block)
   const int DP = a.DP, Lp = a.LpPack;
   const int lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+#ifdef BNPVI_TABLATE_B0_NOPACKALL
+  if (K > 0) return;
+#endif
   // fp32 rows for the E-step's exact-recompute path: coalesced
   for (int e = tid; e < Lp * DP; e += T) {
     const int leaf = e / DP, d = e % DP;
     a.a32[e] = (leaf < L && d < D) ? (float)al[node_of_leaf[leaf] * D + d] : 0.f;
   }
-  // ||alpha||^2 and max|alpha|: ONE THREAD per leaf walking its row in LDS (a wave per leaf with
-  // a 6-step fp64 shuffle reduction per row was the longest phase of this workgroup); the walk
-  // starts at a lane-dependent dimension so that the lanes of a wave hit different banks
+  // ||alpha||^2 and max|alpha|: FOUR threads per leaf, each walking a quarter of the row in LDS (one thread per
+  // leaf took 1.9 us of this workgroup's ~16 us chain at config 2; a wave per leaf with a 6-step fp64 shuffle
+  // reduction per row was slower still); the walk starts at a leaf-dependent dimension so that the lanes of a
+  // wave hit different banks
   float amax = 0.f, aamax = 0.f;
-  for (int leaf = tid; leaf < Lp; leaf += T) {
-    double aa = 0.0;
-    if (leaf < L) {
-      const double* row = al + node_of_leaf[leaf] * D;
-      const int start = lane % D;
-      for (int q = 0; q < D; ++q) {
-        int d = start + q;
-        d = d >= D ? d - D : d;
-        const float f = (float)row[d];
-        aa = fma((double)f, (double)f, aa);
-        amax = fmaxf(amax, fabsf(f));
+  {
+    const int Q = (D + 3) >> 2;
+    for (int u = tid; u < 4 * Lp; u += T) {              // T is a multiple of 4: a leaf's four threads share a wave
+      const int leaf = u >> 2, part = u & 3;
+      double aa = 0.0;
+#ifdef BNPVI_TABLATE_B0_NOAA
+      if (leaf < 0) {
+#else
+      if (leaf < L) {
+#endif
+        const double* row = al + node_of_leaf[leaf] * D;
+        int q = leaf % Q;
+        for (int it = 0; it < Q; ++it) {
+          const int d = part * Q + q;
+          if (d < D) {
+            const float f = (float)row[d];
+            aa = fma((double)f, (double)f, aa);
+            amax = fmaxf(amax, fabsf(f));
+          }
+          q = q + 1 == Q ? 0 : q + 1;
+        }
       }
+      aa += __shfl_xor(aa, 1);
+      aa += __shfl_xor(aa, 2);
+      if (part == 0) a.aavec[leaf] = (float)aa;
+      aamax = fmaxf(aamax, (float)aa);
     }
-    a.aavec[leaf] = (float)aa;
-    aamax = fmaxf(aamax, (float)aa);
   }
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) aamax = fmaxf(aamax, __shfl_xor(aamax, off));
@@ -709,7 +729,7 @@ int launch_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* t, const double* stats
   a.level_nodes = t->d_level_nodes; a.level_ptr = t->d_level_ptr; a.parent = t->d_parent;
   a.leaf_of_node = t->d_leaf_of_node; a.node_of_leaf = t->d_node_of_leaf; a.child_ptr = t->d_child_ptr;
   a.child_idx = t->d_child_idx; a.leaf_lo = t->d_leaf_lo; a.leaf_hi = t->d_leaf_hi;
-  a.nlevels = t->nlevels; a.K = t->K; a.L = t->L; a.Lp = t->Lp;
+  a.nlevels = t->nlevels; a.K = t->K; a.L = t->L; a.Lp = t->Lp; a.internal_levels = t->internal_levels;
   a.stats = stats; a.W = W; a.D = D; a.sB = sB; a.sZ = sZ; a.alpha0 = alpha0; a.alpha = alpha; a.sigma = sigma;
   a.mass = mass; a.V = V; a.gamma_hyper = gamma_hyper; a.gamma = gamma; a.prior = prior;
   a.stick_waves = stick_waves;
