@@ -98,7 +98,11 @@ int bnpvi_tree_leaf_nodes(const bnpvi_tree* tree, int32_t* out_host);
  *                multi-GPU caller all-reduces (RCCL, sum, fp64) before bnpvi_node_params.
  *   mass_dev   : double [V][L] or NULL:  m[v,l] = sum_{n in video v} phi[n,l]
  * fp32 MFMA products, fp32 partial sums over <= 8192 frames, fp64 accumulation above that;
- * partial slabs are combined in a fixed order (bit-reproducible run to run). */
+ * partial slabs are combined in a fixed order (bit-reproducible run to run).  The products are exact
+ * (operands split into three bf16 pieces, six matrix products) except for trees whose padded leaves x padded
+ * dims reach 1024 x 256, where the matrix pipe bounds the pass: there the operands are scaled by powers of two
+ * and split into two f16 pieces good to 2^-22 (three products, one extra read of Z for max|Z|); measured
+ * against fp64 the statistics are as close as with the exact split (the fp32 partial sums dominate both). */
 int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* phi_dev,
                      int ldphi, const int32_t* vid_dev, int64_t N, int D, int L, int V,
                      int want_q, double* stats_dev, double* mass_dev, void* stream);
@@ -184,7 +188,10 @@ int bnpvi_params_prior(bnpvi_ctx* ctx, const bnpvi_tree* tree, const double* sta
  *   estats_dev : double [L][2] or NULL        S0' = sum_n phi, S2 = sum_n phi*||z-alpha||^2 (left 0 under
  *                                             BNPVI_ESTEP_STATS_S0 where the kernel does not carry it)
  *                                             (mean(phi) and stdev of src/var_inf.py:194,217-220)
- * mode BNPVI_ESTEP_HARD ignores prior and writes the one-hot nearest-leaf matrix. */
+ * mode BNPVI_ESTEP_HARD ignores prior and writes the one-hot nearest-leaf matrix.
+ * Workspace (owned by the context, grown on demand, freed by bnpvi_ctx_destroy): the packed leaf operands; for
+ * trees whose operands do not fit the LDS (thousands of leaves) also per-(frame, 128-leaf chunk) softmax
+ * partials and, in soft mode, an image of Z in matrix-operand order (N * ldz * 4 bytes). */
 int bnpvi_estep(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* Z_dev, int ldz,
                 const int32_t* vid_dev, int64_t N, int D, const double* alpha_dev,
                 const float* prior_dev, double sigma_z_sqrinv, int mode, float* phi_dev,
