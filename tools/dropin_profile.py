@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 from bnp_vae_amd import VarInf  # noqa: E402
 
+PROFILE_CALL = -1   # --profile-call=N: which call --profile looks at (default: the last)
 COMPS = 0           # --comps=N: mixture components of config 5's workload (default 24)
 SHAPES = {
     # name: (N, D, branching, levels, stdev_thr, num_splits, calls, frames per video)
@@ -90,7 +91,7 @@ def dropin_calls(name, N, calls, profile, dev):
     for call in range(calls):
         Z = latents(N, D, mu, call, dev, noise)
         torch.cuda.synchronize()
-        if profile and call == calls - 1:
+        if profile and call == (PROFILE_CALL if PROFILE_CALL >= 0 else calls - 1):
             pr = cProfile.Profile()
             pr.enable()
         t0 = time.perf_counter()
@@ -101,7 +102,7 @@ def dropin_calls(name, N, calls, profile, dev):
             pr.disable()
         ks.append(len(vi._preorder()))
     if pr is not None:
-        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(30)
     del vi
     torch.cuda.empty_cache()
     return times, ks
@@ -163,6 +164,8 @@ if __name__ == "__main__":
     for a in sys.argv[1:]:
         if a.startswith("--comps="):
             COMPS = int(a.split("=")[1])
+        if a.startswith("--profile-call="):
+            PROFILE_CALL = int(a.split("=")[1])
         if a.startswith("--calls="):                      # e.g. --calls=16: a longer dynamic run of config 5
             SHAPES["config5"] = SHAPES["config5"][:6] + (int(a.split("=")[1]),) + SHAPES["config5"][7:]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
