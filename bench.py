@@ -302,11 +302,12 @@ class Runner(object):
             # large trees (config 4): both data passes are matrix-pipe problems.  Algorithmic flops per launch =
             # the one dense contraction of the kernel, 2 L D per frame (E: z . alpha^T, M: R^T Z); the kernels
             # issue 3 products per algorithmic one (f16 hi/lo split; the M-step's wide kernel takes that split where
-            # the padded tree has >= 1024 x 256 leaf x dim entries, else the exact bf16 x 3 split with 6) to keep
+            # the padded tree has >= 512 x 256 leaf x dim entries, else the exact bf16 x 3 split with 6) to keep
             # fp32 accuracy.  Peak: dense bf16 / f16 MFMA, MI355X_MICROARCH.md.  (The E-step timer covers the fragment
             # pre-pass and the logits kernel -- pass A -- of the streamed regime only.)
             flops = 2.0 * N * L * D
-            m_issued = 3.0 if (-(-L // 32) * 32) * (256 if D > 128 else 0) >= 1024 * 256 else 6.0
+            Dp = 32 if D <= 32 else 64 if D <= 64 else 128 if D <= 128 else 256
+            m_issued = 3.0 if Dp >= 128 and (-(-L // 32) * 32) * Dp >= 512 * 256 else 6.0
             issued = {"estep": 3.0, "mstep_stats": m_issued}[dom]
             roof.update({"bound": "mfma", "achieved": flops / (dom_ms * 1e-3) / 1e12, "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / (dom_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,

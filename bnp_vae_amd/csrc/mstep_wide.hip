@@ -32,6 +32,10 @@ namespace bnpvi {
 
 constexpr int kWideWaves = 4;
 constexpr int kWideRing = 3;
+// padded leaves x padded dims from which the two-piece f16 split is taken (500k frames, kernel us, exact -> f16:
+// D=128 L=1024 773 -> 565, L=4096 2834 -> 1764; D=256 L=256 426 -> 391 (call time 417 -> 435: the max|Z| pass),
+// L=512 726 -> 561, L=1296 1868 -> 1216; D=200 L=3125 4516 -> 2787)
+constexpr int64_t kWideF16From = (int64_t)512 * 256;
 
 template <int LBW, int DBW, int TL, int TD>   // waves and 32-wide tiles per wave: leaves, dims
 struct WideSlot {
@@ -576,14 +580,17 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
   // 512 x 128 at D <= 128, 512 x 64 at D <= 64.  Thresholds measured against the per-wave ring of
   // mstep_dma.hip (1M frames, kernel us, ring -> wide): D=256 L=256 993 -> 737, L=343 1637 -> 1196;
   // D=128 L=512 1040 -> 787, L=625 1606 -> 1267; D=64 L=512 (2M frames) 1113 -> 993.
-  // F16 mode (three products instead of six) where the matrix pipe bounds the pass: D padded to 256 and
-  // thousands of leaves (config 4).  Smaller trees are HBM-bound and keep the exact split.
+  // F16 mode (three products instead of six) where the matrix pipe bounds the pass (kWideF16From); smaller trees
+  // are HBM-bound and keep the exact split.
   const char* env = dev_getenv("BNPVI_WIDE_F16");                       // development switch: "off" / "on"
-  const bool f16 = env ? strcmp(env, "off") != 0 : ((int64_t)ldphi * ldz >= (int64_t)1024 * 256);
-  if (ldz % 256 == 0 && ldphi >= 256 && f16 && ctx->small != nullptr && (((uintptr_t)Z) & 15) == 0)
+  const bool can16 = ctx->small != nullptr && (((uintptr_t)Z) & 15) == 0;
+  const bool f16 = can16 && (env ? strcmp(env, "off") != 0 : ((int64_t)ldphi * ldz >= kWideF16From));
+  if (ldz % 256 == 0 && ldphi >= 256 && f16)
     return run_wide<2, 2, 4, 4, true>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz % 256 == 0 && ldphi >= 256)
     return run_wide<2, 2, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  if (ldz % 128 == 0 && ldphi >= 512 && f16)
+    return run_wide<4, 1, 4, 4, true>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz % 128 == 0 && ldphi >= 512)
     return run_wide<4, 1, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   if (ldz == 64 && ldphi >= 512) return run_wide<4, 1, 4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);

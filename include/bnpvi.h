@@ -100,7 +100,7 @@ int bnpvi_tree_leaf_nodes(const bnpvi_tree* tree, int32_t* out_host);
  * fp32 MFMA products, fp32 partial sums over <= 8192 frames, fp64 accumulation above that;
  * partial slabs are combined in a fixed order (bit-reproducible run to run).  The products are exact
  * (operands split into three bf16 pieces, six matrix products) except for trees whose padded leaves x padded
- * dims reach 1024 x 256, where the matrix pipe bounds the pass: there the operands are scaled by powers of two
+ * dims reach 512 x 256, where the matrix pipe bounds the pass: there the operands are scaled by powers of two
  * and split into two f16 pieces good to 2^-22 (three products, one extra read of Z for max|Z|); measured
  * against fp64 the statistics are as close as with the exact split (the fp32 partial sums dominate both). */
 int bnpvi_leaf_stats(bnpvi_ctx* ctx, const float* Z_dev, int ldz, const float* phi_dev,

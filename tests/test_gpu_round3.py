@@ -354,12 +354,13 @@ def test_widely_spread_leaves_stay_on_the_common_path_within_fp32_resolution(N, 
 
 
 @pytest.mark.parametrize("N,D,bf,levels,zscale", [
-    (6000, 256, 6, 4, 1.0),        # L = 1296 -> padded 1312 x 256: the smallest tree on the f16 path
+    (6000, 256, 6, 4, 1.0),        # L = 1296 -> padded 1312 x 256
+    (7000, 128, 4, 5, 1.0),        # D = 128, L = 1024: the 512 x 128 tile, the smallest tree on the f16 path
     (5003, 200, 4, 5, 300.0),      # ragged N, D padded 200 -> 256, latents far from unit scale
     (4000, 256, 6, 5, 1e-3),       # config 4's tree, tiny latents (the scale exponent goes the other way)
 ])
 def test_wide_mstep_two_piece_f16_split_against_fp64(N, D, bf, levels, zscale):
-    """mstep_wide.hip, F16 mode (matrix-pipe-bound trees: padded leaves x padded dims >= 1024 x 256): operands
+    """mstep_wide.hip, F16 mode (matrix-pipe-bound trees: padded leaves x padded dims >= 512 x 256): operands
     scaled by powers of two (max|Z| found by a pre-pass) and split into two f16 pieces, three products.  S1 = phi^T Z
     against torch fp64 to 1e-6 of its largest entry (the operands are good to 2^-22; the rest is the fp32
     accumulation every M-step kernel has), S0 and the per-video masses against the column sums."""
@@ -369,7 +370,7 @@ def test_wide_mstep_two_piece_f16_split_against_fp64(N, D, bf, levels, zscale):
     from bnp_vae_amd.engine import DeviceVI
     parent, is_leaf = regular_tree(bf, levels)
     K, L = len(parent), int(is_leaf.sum())
-    assert _lib.padded_leaves(L) * _lib.padded_dim(D) >= 1024 * 256
+    assert _lib.padded_leaves(L) * _lib.padded_dim(D) >= 512 * 256
     dev = DeviceVI(device=0)
     Z, vid, V = make_latents(torch, dev.device, N, D, L, 0)
     dev.set_latents(Z * zscale, vid, V)
