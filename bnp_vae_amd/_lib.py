@@ -17,6 +17,7 @@ ESTEP_SOFT = 0
 ESTEP_HARD = 1
 ESTEP_OPERANDS_READY = 0x100
 ESTEP_STATS_S0 = 0x200
+EUNSUPPORTED = 4          # BNPVI_EUNSUPPORTED: the entry point does not take this shape (the caller has another way)
 
 
 class BnpviError(RuntimeError):
@@ -71,6 +72,7 @@ EXPORTS = {
     "bnpvi_leaf_s2": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _i, _p, _p]),
     "bnpvi_kmeans_pass_multi": (_i, [_p, _p, _i, _i64, _i, _p, _i, _i, _p, _i, _p, _i, _p, _p, _p, _p]),
     "bnpvi_kmeans_max_columns": (_i, [_i]),
+    "bnpvi_kmeans_first_nested": (_i, [_p, _p, _p, _i, _i64, _p, _i, _p, _p, _p]),
     "bnpvi_path_distances": (_i, [_p, _p, _p, _i, _i64, _i, _p, _p, _i, _p, _p, _p]),
     "bnpvi_remap_columns": (_i, [_p, _p, _i, _p, _i, _i64, _i, _p, _p, _p]),
 }

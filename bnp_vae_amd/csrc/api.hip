@@ -411,6 +411,16 @@ int bnpvi_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, 
                                   best_score, (hipStream_t)stream);
 }
 
+int bnpvi_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* phi, int ldphi, int64_t N,
+                              const int32_t* cols, int J, int64_t* best_row, double* best_score, void* stream) {
+  BNPVI_REQUIRE(ctx && tree && phi && cols && best_row && best_score, "bnpvi_kmeans_first_nested: NULL argument");
+  BNPVI_REQUIRE(N >= 1 && ldphi >= tree->L, "bnpvi_kmeans_first_nested: N=%lld ldphi=%d (L=%d)", (long long)N, ldphi,
+                tree->L);
+  BNPVI_REQUIRE(J >= 1 && J <= 64, "bnpvi_kmeans_first_nested: J=%d columns, at most 64 per call", J);
+  BNPVI_HIP(hipSetDevice(ctx->device));
+  return launch_kmeans_first_nested(ctx, tree, phi, ldphi, N, cols, J, best_row, best_score, (hipStream_t)stream);
+}
+
 int bnpvi_kmeans_max_columns(int D) {
   const int G = bnpvi_padded_dim(D) / 4;
   return G < 64 ? G : 64;

@@ -162,6 +162,8 @@ int launch_estep(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz,
 int launch_path_distances(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* Z, int ldz, int64_t N, int D,
                           const double* alpha, const int32_t* assign, int max_depth, int32_t* node_out,
                           double* dist_out, hipStream_t s);
+int launch_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* phi, int ldphi, int64_t N,
+                               const int32_t* cols, int J, int64_t* best_row, double* best_score, hipStream_t s);
 int launch_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* phi,
                              int ldphi, int L, const int32_t* cols, int J, const float* centres, int first,
                              float* dist2, int64_t* best_row, double* best_score, hipStream_t s);

@@ -939,6 +939,121 @@ __global__ __launch_bounds__(256) void kmeans_final_multi_kernel(const Best* __r
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// First centres with the reference's OWN rounding of the responsibilities.  The reference normalises a row as
+// phi = exp(logit - max) / phi_sum with phi_sum = get_phi_sum(root) (src/var_inf.py:336-343, 391-392): an fp64 sum
+// NESTED like the tree (every internal node adds its children in order, starting from 0).  For a frame its leaf
+// dominates, exp(0) = 1 sits somewhere inside that nest and the other leaves' tiny terms are absorbed or not
+// depending on WHERE they meet it: a frame with five terms of 5e-17 each reads phi = 1.0 exactly when they are
+// added to the 1 one by one, 1 - 2.2e-16 when they meet each other first.  np.argmax then takes the lowest row
+// among equal doubles, so on well-separated data (many rows at or near 1.0) the choice of the first centre hangs on
+// that rounding -- a flat 1 / (1 + c) picked another frame in 2 of 29 splits of a random trajectory
+// (tests/test_gpu_round3.py::test_random_trajectories_against_oracle).  Here the nest is replayed: per dominated
+// row one wave writes x_l = phi_l / phi_col (fp64; the column itself exactly 1) into an LDS image of the tree's
+// nodes and sums it level by level, children in order, one lane per internal node; score = 1 / phi_sum as the
+// reference divides.  The fp32 phi_l carry the kernels' relative error (~3e-5), which moves a sum across a rounding
+// boundary only when it sits within that distance of one.  The later factors of weighted_kmeans (weights / sum,
+// * 1/N, normalize()) are monotone and cannot be replayed bit for bit (np.sum over all frames); they can only merge
+// neighbouring doubles, which is left as a near-tie.
+// ------------------------------------------------------------------------------------------
+struct NestTree {
+  const int32_t *node_of_leaf, *leaf_of_node, *child_ptr, *child_idx, *level_ptr, *level_nodes;
+  int K, L, internal_levels;
+};
+
+__global__ __launch_bounds__(256) void kmeans_first_nested_kernel(const float* __restrict__ phi, int ldphi, int64_t N,
+                                                                  NestTree t, const int32_t* __restrict__ cols, int J,
+                                                                  Best* __restrict__ part32,
+                                                                  Best64* __restrict__ part64) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ Best sh32[4][64];
+  __shared__ Best64 sh64[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* val = reinterpret_cast<double*>(smem_raw) + (size_t)wave * t.K;     // this wave's image of the nodes
+  const int mycol = lane < J ? cols[lane] : 0;
+  Best b32;
+  b32.score = -1.f;
+  b32.row = 0x7fffffffffffffffLL;
+  Best64 b64;
+  b64.score = -1.0;
+  b64.row = 0x7fffffffffffffffLL;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + wave; n < N; n += (int64_t)gridDim.x * 4) {
+    const float* row = phi + n * ldphi;
+    const float wn = lane < J ? row[mycol] : -1.f;
+    if (lane < J && better(wn, n, b32.score, b32.row)) {
+      b32.score = wn;
+      b32.row = n;
+    }
+    unsigned long long mask = __ballot(lane < J && wn >= kDominant);
+    while (mask != 0ull) {                                     // wave-uniform; at most one leaf dominates a row
+      const int jl = __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      const int col = __builtin_amdgcn_readlane(mycol, jl);
+      const double pc = (double)__uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(wn), jl));
+      for (int l = lane; l < t.L; l += 64) val[t.node_of_leaf[l]] = l == col ? 1.0 : (double)row[l] / pc;
+      wave_sync_lds();
+      for (int lev = t.internal_levels - 1; lev >= 0; --lev) {
+        for (int i = t.level_ptr[lev] + lane; i < t.level_ptr[lev + 1]; i += 64) {
+          const int k = t.level_nodes[i];
+          if (t.leaf_of_node[k] < 0) {
+            double acc = 0.0;
+            for (int c = t.child_ptr[k]; c < t.child_ptr[k + 1]; ++c) acc += val[t.child_idx[c]];
+            val[k] = acc;
+          }
+        }
+        wave_sync_lds();
+      }
+      const double s = 1.0 / val[0];
+      wave_sync_lds();                                         // everybody has read val[0] before the next row's image
+      if (lane == jl && better64(s, n, b64.score, b64.row)) {
+        b64.score = s;
+        b64.row = n;
+      }
+    }
+  }
+  sh32[wave][lane] = b32;
+  sh64[wave][lane] = b64;
+  __syncthreads();
+  if (wave == 0 && lane < J) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const Best o = sh32[w][lane];
+      if (better(o.score, o.row, b32.score, b32.row)) b32 = o;
+      const Best64 o64 = sh64[w][lane];
+      if (better64(o64.score, o64.row, b64.score, b64.row)) b64 = o64;
+    }
+    part32[(int64_t)blockIdx.x * J + lane] = b32;
+    part64[(int64_t)blockIdx.x * J + lane] = b64;
+  }
+}
+
+constexpr size_t kNestLdsMax = 96 * 1024;      // 4 waves x K doubles: trees of up to 3072 nodes
+
+int launch_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* phi, int ldphi, int64_t N,
+                               const int32_t* cols, int J, int64_t* best_row, double* best_score, hipStream_t s) {
+  const size_t lds = (size_t)4 * t->K * sizeof(double);
+  if (lds > kNestLdsMax) return BNPVI_EUNSUPPORTED;
+  int64_t blocks = ceil_div(N, (int64_t)4);
+  const int64_t cap = (int64_t)ctx->num_cu * 8;
+  if (blocks > cap) blocks = cap;
+  int rc = ctx->red.ensure((size_t)blocks * J * (sizeof(Best) + sizeof(Best64)));
+  if (rc) return rc;
+  Best64* p64 = (Best64*)ctx->red.ptr;          // 16-byte records first
+  Best* p32 = (Best*)(p64 + blocks * J);
+  NestTree nt{t->d_node_of_leaf, t->d_leaf_of_node, t->d_child_ptr, t->d_child_idx, t->d_level_ptr, t->d_level_nodes,
+              t->K, t->L, t->internal_levels};
+  if (lds > 48 * 1024)
+    BNPVI_HIP(hipFuncSetAttribute((const void*)kmeans_first_nested_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+  hipLaunchKernelGGL(kmeans_first_nested_kernel, dim3((unsigned)blocks), dim3(256), lds, s, phi, ldphi, N, nt, cols, J,
+                     p32, p64);
+  BNPVI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(kmeans_final_multi_kernel, dim3(J), dim3(256), 0, s, p32, p64, (int)blocks, J, best_row,
+                     best_score);
+  BNPVI_LAUNCH_CHECK();
+  return BNPVI_OK;
+}
+
 // sum over the G lanes that share a row (G = 8 .. 64, aligned lane groups): DPP inside a 16-lane row,
 // permlane swaps across rows.  Every lane of the group returns the same bits.
 template <int G>

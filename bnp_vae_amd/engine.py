@@ -373,7 +373,17 @@ class DeviceVI(object):
         picked = []                                                  # per pass: [J, Dp] fp32 rows of Z
         rows = []                                                    # per pass: [J] (global) row indices
         for k in range(num_centres):
-            if N > 0:
+            nested = False
+            if N > 0 and k == 0 and responsibilities:
+                # first centres with the reference's nested fp64 row sums (trees of up to 3072 nodes)
+                rc = lib.bnpvi_kmeans_first_nested(self.ctx, self.tree.handle, _ptr(self.phi), int(self.phi.shape[1]),
+                                                   N, _ptr(cols_t), J, _ptr(best_row), _ptr(best_score),
+                                                   self._stream())
+                if rc == 0:
+                    nested = True
+                elif rc != _lib.EUNSUPPORTED:
+                    check(rc, "bnpvi_kmeans_first_nested")
+            if N > 0 and not nested:
                 check(lib.bnpvi_kmeans_pass_multi(self.ctx, _ptr(self.Z), Dp, N, D, _ptr(self.phi),
                                                   int(self.phi.shape[1]), int(self.tree.L) if responsibilities else 0,
                                                   _ptr(cols_t), J,

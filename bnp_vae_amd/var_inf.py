@@ -409,6 +409,13 @@ class VarInf(object):
             self._build_initial_tree()
             self._replicate_initial_alpha()
             self._one_hot_init(Z)
+        elif self.root.isLeafNode:
+            # The tree has collapsed to its root (merge_nodes pruned every child, src/var_inf.py:200-201).  The
+            # reference cannot go on from there: compute_gamma_node sets the leaf root's gamma to None (:397-399) and
+            # compute_gamma_sum_before then indexes it (:372-373, digamma_add1) -- TypeError.  Same error here,
+            # raised before anything is launched.
+            raise TypeError("'NoneType' object is not subscriptable (the tree has collapsed to its root: the "
+                            "reference fails in compute_gamma_sum_before, src/var_inf.py:372-373)")
         self._load_latents(Z)
         self._ensure_tree()                  # full check once; inside, only flagged changes re-flatten
         self._trusted += 1

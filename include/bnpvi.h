@@ -241,6 +241,17 @@ int bnpvi_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z_dev, int ldz, int64_t
                             const float* centres_dev, int first, float* dist2_dev,
                             int64_t* best_row_dev, double* best_score_dev, void* stream);
 int bnpvi_kmeans_max_columns(int D);
+/* First centres (src/var_inf.py:29-30) for J <= 64 columns of a responsibility matrix that came straight from
+ * bnpvi_estep on `tree`, with the reference's own rounding: for every frame a listed leaf dominates (fp32
+ * phi >= 0.5) the fp64 sum get_phi_sum(root) of src/var_inf.py:336-343 is replayed in the TREE'S nesting order
+ * (x_l = phi_l / phi_col, the column itself exactly 1) and the score is 1 / that sum, as the reference's
+ * normalisation divides (:345-349) -- on well-separated data, where many rows read 1.0 or a few ulps below, which
+ * of them np.argmax sees first depends on where in that nest the tiny terms are absorbed.  Below 0.5: fp32
+ * arg-max.  Lowest row on ties.  Returns BNPVI_EUNSUPPORTED for trees of more than 3072 nodes (the caller then
+ * uses bnpvi_kmeans_pass_multi with centres_dev == NULL). */
+int bnpvi_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* tree, const float* phi_dev, int ldphi,
+                              int64_t N, const int32_t* cols_dev, int J, int64_t* best_row_dev,
+                              double* best_score_dev, void* stream);
 
 /* ---- distances of every frame to the nodes on the path of its leaf ---------------------------
  * The per-node ranking of src/create_hierarchy.py:40-53 ("top-K closest frames" of a node among

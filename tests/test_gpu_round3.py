@@ -389,6 +389,19 @@ def test_wide_mstep_two_piece_f16_split_against_fp64(N, D, bf, levels, zscale):
     dev.close()
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 5, 8, 9, 12, 17, 20, 25, 29, 44])
+def test_random_trajectories_against_oracle(seed):
+    """tests/traj_fuzz.py: a seed draws D (8 .. 128), the initial tree (2- to 5-ary, 1-3 levels), num_splits, a
+    mixture, ragged videos and a split threshold; five calls with fresh latents, structure + parameters + phi
+    against OracleVarInf after every call.  The seeds cover growth to K = 258 (44), shrinking to K = 6 (12), a tree
+    that collapses to its root, where the reference -- and the product -- raise TypeError on the next call (1), and
+    the split whose first centres hang on the reference's nested fp64 row sums (9: bnpvi_kmeans_first_nested).
+    Out of 500 seeds swept with the same helper three differ, each at an fp32 near-tie of a k-means arg-max."""
+    from tests.traj_fuzz import one
+    tag, res = one(seed)
+    assert res.startswith("ok"), tag + " -> " + res
+
+
 def _run_workers(world, spec, tmp_path, timeout=900):
     import socket
     import subprocess
