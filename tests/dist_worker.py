@@ -6,6 +6,8 @@ dist.shard_videos, runs the golden trajectory through VarInf(group=...) and writ
 holds after every epoch.
 
   python tests/dist_worker.py RANK WORLD PORT OUTDIR GOLDEN
+  python tests/dist_worker.py RANK WORLD PORT OUTDIR fuzz:SEED
+      the random trajectory tests/traj_fuzz.py draws for SEED, this rank's videos of it (tests/dist_fuzz.py)
   python tests/dist_worker.py RANK WORLD PORT OUTDIR synth:N:D:COMPS:CALLS:BF:LEVELS
       full-size synthetic run (test_gpu_round3.py): the rank's share of N clustered frames, built on the
       device from a formula of the GLOBAL row index (the same data whatever the sharding); writes the tree ids
@@ -65,6 +67,38 @@ def synth(rank, world, out_dir, spec, group):
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
 
 
+def fuzz(rank, world, out_dir, spec, group):
+    import numpy as np
+    from bnp_vae_amd import VarInf
+    from bnp_vae_amd import dist as vdist
+    from tests.traj_fuzz import config, latents
+    seed = int(spec.split(":")[1])
+    kw, N, D, mu, noise, fpv, _tag = config(seed)
+    v0, v1, f0, f1 = vdist.shard_videos(fpv, world)[rank]
+    starts = np.concatenate([[0], np.cumsum(fpv)])
+    np.random.seed(1000 + rank)
+    vi = VarInf(group=group, **kw)
+    out = {"f0": f0, "f1": f1}
+    for ep in range(5):
+        Z = latents(N, D, mu, ep, seed, noise)
+        lc = {}
+        for v in range(v0, v1):
+            lc["vid%05d" % v] = {"%06d" % f: Z[starts[v] + f] for f in range(fpv[v])}
+        if rank == 0:
+            np.random.seed(13 + ep)
+        try:
+            vi.update_variational_parameters(lc)
+        except TypeError:
+            out["e%d_raised" % ep] = 1                       # the tree collapsed to its root a call earlier
+            break
+        nodes = vi.get_nodes_list(vi.root, [])
+        out["e%d_ids" % ep] = np.asarray([n.node_id for n in nodes])
+        out["e%d_is_leaf" % ep] = np.asarray([bool(n.isLeafNode) for n in nodes])
+        out["e%d_alpha" % ep] = np.asarray([np.asarray(n.alpha) for n in nodes])
+        out["e%d_sigma" % ep] = np.asarray([float(n.sigmasqr_inv) for n in nodes])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+
+
 def main():
     rank, world, port, out_dir, golden = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -78,6 +112,10 @@ def main():
     from bnp_vae_amd import VarInf
     from bnp_vae_amd import dist as vdist
     from oracle.vi_oracle import snapshot, drifting_latents
+    if golden.startswith("fuzz:"):
+        fuzz(rank, world, out_dir, golden, dist.group.WORLD if world > 1 else None)
+        dist.destroy_process_group()
+        return
     if golden.startswith("synth:"):
         synth(rank, world, out_dir, golden, dist.group.WORLD if world > 1 else None)
         dist.destroy_process_group()

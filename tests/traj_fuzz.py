@@ -3,7 +3,8 @@ test_random_trajectories_against_oracle, and a sweep on its own: `python tests/t
 
 A seed fixes D, the initial tree, num_splits, the mixture, N, the video lengths and the split threshold; five calls
 with fresh drifting latents; after every call the product must have the oracle's tree, node parameters (1e-4 of
-the largest alpha, 1e-4 of each sigma) and phi (2e-4).  When the tree collapses to its root the reference raises
+the largest alpha, 1e-4 of each sigma) and phi (2e-4); on the final tree the offline tools of SURVEY 8(f) (per-node
+closest frames, class vote) are compared with oracle/hierarchy_oracle.py.  When the tree collapses to its root the reference raises
 TypeError on the next call (src/var_inf.py:372-373) and so must the product.
 Sweep of 500 seeds (round 3): 3 differ, each at a near-tie of a k-means arg-max inside the accuracy of the fp32
 responsibilities (relative gap between the two frames' scores 4e-7, 4e-7 and 1.7e-6: seeds 175, 222, 362); none in
@@ -24,8 +25,8 @@ def latents(N, D, mu, ep, seed, noise):
     return (mu[comp] * (1.0 + 0.02 * ep) + eps).astype(np.float32)
 
 
-def one(seed, verbose=True):
-    from bnp_vae_amd import VarInf
+def config(seed):
+    """Everything a seed fixes: (VarInf keywords, N, D, mixture means, noise, frames per video, tag)."""
     rng = np.random.RandomState(seed)
     D = int(rng.choice([8, 32, 64, 100, 128]))
     bf, levels, ns = int(rng.randint(2, 6)), int(rng.randint(1, 4)), int(rng.randint(2, 5))
@@ -42,8 +43,14 @@ def one(seed, verbose=True):
         fpv.pop()
     mu = rng.normal(scale=spread, size=(ncomp, D))
     kw = dict(latent_code_size=D, stdev_thr=thr, num_splits=ns, branching=bf, levels=levels)
-    ora, vi = OracleVarInf(**kw), VarInf(**kw)
     tag = "seed %d: N=%d D=%d bf=%d levels=%d ns=%d comps=%d noise=%g thr=%.3g" % (seed, N, D, bf, levels, ns, ncomp, noise, thr)
+    return kw, N, D, mu, noise, fpv, tag
+
+
+def one(seed, verbose=True):
+    from bnp_vae_amd import VarInf
+    kw, N, D, mu, noise, fpv, tag = config(seed)
+    ora, vi = OracleVarInf(**kw), VarInf(**kw)
     ks = []
     for ep in range(5):
         Z = latents(N, D, mu, ep, seed, noise)
@@ -72,7 +79,53 @@ def one(seed, verbose=True):
         dp = float(np.abs(got['phi'] - want['phi']).max())
         if da > 1e-4 or ds > 1e-4 or dp > 2e-4:
             return tag, "VALUES differ after call %d: alpha %.2e sigma %.2e phi %.2e (K %s)" % (ep, da, ds, dp, ks)
+    extra = offline_tools(vi, Z, seed)
+    if extra:
+        return tag, "OFFLINE TOOLS differ on the final tree (K %s): %s" % (ks, extra)
     return tag, "ok (K per call %s)" % ks
+
+
+def offline_tools(vi, Z, seed):
+    """SURVEY 8(f) rows on the tree the trajectory ended with: per-node closest frames and the class vote against
+    oracle/hierarchy_oracle.py; an assignment may differ only at a near-tie of the two nearest leaves."""
+    from bnp_vae_amd.hierarchy import closest_frames, class_vote
+    from oracle.hierarchy_oracle import closest_frames as o_closest, class_vote as o_vote, dfs_leaves
+    nodes = vi.get_nodes_list(vi.root, [])
+    leaves = dfs_leaves(vi.root)
+    if len(leaves) < 2:
+        return ""
+    alpha = np.asarray([l.alpha for l in leaves], dtype=np.float64)
+    rng = np.random.RandomState(seed + 77)
+    z = np.concatenate([Z[:400], Z[:25]]).astype(np.float32)            # duplicates: stable tie order
+    d = np.linalg.norm(alpha[None] - z[:, None].astype(np.float64), axis=2)
+    for K in (1, 6):
+        assign, top = closest_frames(nodes, z, K)
+        want_assign, want_top = o_closest(vi.root, z.astype(np.float64), K)
+        for i in np.nonzero(assign != want_assign)[0]:
+            if abs(d[i, assign[i]] - d[i, want_assign[i]]) > 1e-5 * max(1.0, d[i].min()):
+                return "closest_frames: frame %d assigned to leaf %d, oracle %d, distances %.9g / %.9g" % (
+                    i, assign[i], want_assign[i], d[i, assign[i]], d[i, want_assign[i]])
+        if np.array_equal(assign, want_assign):
+            for n in want_top:
+                if top[n] != want_top[n]:
+                    return "closest_frames K=%d: node %s has %s, oracle %s" % (K, n.node_id, top[n][:6], want_top[n][:6])
+    z_train, z_test = Z[:300].astype(np.float32), Z[300:900].astype(np.float32)
+    labels = rng.randint(0, 4, size=len(z_train))
+    for decay in (0.0, 0.5):
+        p2c, pred = class_vote(nodes, z_train, labels, z_test, decay_factor=decay)
+        want_p2c, want_pred = o_vote(vi.root, z_train.astype(np.float64), labels, z_test.astype(np.float64), decay)
+        dtr = np.linalg.norm(alpha[None] - z_train[:, None].astype(np.float64), axis=2)
+        srt = np.sort(dtr, axis=1)
+        if np.any(srt[:, 1] - srt[:, 0] <= 1e-5 * np.maximum(1.0, srt[:, 0])):
+            continue                                   # a training frame on a near-tie: the vote table may differ
+        if not np.array_equal(p2c, want_p2c):
+            return "class_vote decay %g: path2class differs at leaves %s" % (decay, list(np.nonzero(p2c != want_p2c)[0][:6]))
+        dte = np.linalg.norm(alpha[None] - z_test[:, None].astype(np.float64), axis=2)
+        for i in np.nonzero(pred != want_pred)[0]:
+            tied = dte[i] - dte[i].min() <= 1e-5 * max(1.0, dte[i].min())
+            if pred[i] not in set(p2c[tied]):
+                return "class_vote decay %g: test frame %d predicted %d, oracle %d" % (decay, i, pred[i], want_pred[i])
+    return ""
 
 
 if __name__ == "__main__":
