@@ -570,7 +570,11 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
   auto more_loads = [&]() {
     if (TV > 0 && soft_only) {
 #pragma unroll
+#ifdef BNPVI_ABLATE_NOPRIORLOAD   // development only: no prior loads at all (results are garbage)
+      for (int T = 0; T < NT; ++T) pre[T] = make_float4(-1.f * T, -2.f, -3.f, -0.5f * lane);
+#else
       for (int T = 0; T < NT; ++T) pre[T] = *reinterpret_cast<const float4*>(prow + kLT * T + 4 * (lane >> 4));
+#endif
     }
     if (FULL || (!HARD && next_tile < ntiles)) {
       const int64_t n2 = next_tile * kFT + j;
