@@ -80,23 +80,28 @@ __global__ __launch_bounds__(1024) void leaf_operands_small_kernel(
 // ------------------------------------------------------------------------------------------
 // Streamed regime, pass B: combine the partials of a frame, normalise its row in place,
 // accumulate S0' / S2.  One wave per row at a time, lanes stride the row in float4.
+// Statistics: a leaf's column is always taken by the same lane of a wave, so every wave keeps its own
+// fp32 table [Lp][2] in LDS (plain read-modify-write, rows in the wave's fixed order); the workgroup's waves are
+// added in order into one fp64 slab per workgroup, the slabs by slab_reduce -- no atomics, same bits every run
+// (the fused, row and column-window epilogues were already built that way).
 // ------------------------------------------------------------------------------------------
 template <bool HARD>
 __global__ __launch_bounds__(256) void estep_normalize_kernel(
     float* __restrict__ phi, float* __restrict__ logphi, int32_t* __restrict__ assign,
     const float2* __restrict__ part, int nchunk, const float* __restrict__ prior,
     const int32_t* __restrict__ vid, int64_t N, int L, int Lp, float inv_half_sz,
-    double* __restrict__ estats /* [L][2] atomically accumulated, or null */) {
+    double* __restrict__ eslab /* [gridDim.x][L][2] one slab per workgroup, or null */) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* st = reinterpret_cast<float*>(smem_raw);        // [Lp][2] fp32 partials of this block
-  const bool want_stats = estats != nullptr;
-  if (want_stats) {
-    for (int e = threadIdx.x; e < 2 * Lp; e += blockDim.x) st[e] = 0.f;
-    __syncthreads();
-  }
+  float* st = reinterpret_cast<float*>(smem_raw);        // [waves][Lp][2] fp32 partials, one table per wave
+  const bool want_stats = eslab != nullptr;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int nw = blockDim.x >> 6;
+  if (want_stats) {
+    for (int e = threadIdx.x; e < nw * 2 * Lp; e += blockDim.x) st[e] = 0.f;
+    __syncthreads();
+  }
+  float* stw = st + (size_t)wave * 2 * Lp;
   for (int64_t n = (int64_t)blockIdx.x * nw + wave; n < N; n += (int64_t)gridDim.x * nw) {
     // combine partials (every lane redundantly walks a strided share, then wave-reduces)
     float m = -INFINITY;
@@ -163,8 +168,8 @@ __global__ __launch_bounds__(256) void estep_normalize_kernel(
             dd = d * d;
           }
           if (pv[c] != 0.f) {
-            atomicAdd(&st[2 * (c4 + c)], pv[c]);
-            atomicAdd(&st[2 * (c4 + c) + 1], pv[c] * dd);
+            stw[2 * (c4 + c)] += pv[c];
+            stw[2 * (c4 + c) + 1] += pv[c] * dd;
           }
         }
       }
@@ -190,8 +195,12 @@ __global__ __launch_bounds__(256) void estep_normalize_kernel(
   }
   if (want_stats) {
     __syncthreads();
-    for (int e = threadIdx.x; e < 2 * L; e += blockDim.x)
-      if (st[e] != 0.f) atomicAdd(&estats[e], (double)st[e]);
+    double* out = eslab + (int64_t)blockIdx.x * 2 * L;
+    for (int e = threadIdx.x; e < 2 * L; e += blockDim.x) {
+      double t = 0.0;
+      for (int w = 0; w < nw; ++w) t += (double)st[(size_t)w * 2 * Lp + e];
+      out[e] = t;
+    }
   }
 }
 
@@ -316,26 +325,46 @@ int estep_finish_streamed(const EstepArgs& a, const float2* part, int nchunk) {
     BNPVI_LAUNCH_CHECK();
     return BNPVI_OK;
   }
-  if (a.estats) BNPVI_HIP(hipMemsetAsync(a.estats, 0, (size_t)2 * L * sizeof(double), a.stream));
-  int64_t nb = ceil_div(a.N, 4);
-  const int64_t capb = (int64_t)a.ctx->num_cu * 8;
+  // hard responsibilities, or the arg-max asked for: the general kernel.  With statistics every wave owns a table of
+  // Lp x 2 floats in LDS, so large trees run fewer waves per workgroup (and one workgroup per CU).
+  int nw = 4;
+  size_t lds = 0;
+  int per_cu = 8;
+  if (a.estats) {
+    const size_t table = (size_t)Lp * 8;
+    BNPVI_REQUIRE(table <= (size_t)kMaxLdsBytes, "estep: L=%d too large for the stats epilogue", L);
+    nw = (int)((size_t)kMaxLdsBytes / table);
+    nw = nw > 4 ? 4 : nw;
+    lds = (size_t)nw * table;
+    per_cu = (int)((size_t)kMaxLdsBytes / lds);
+    per_cu = per_cu > 8 ? 8 : per_cu;
+  }
+  int64_t nb = ceil_div(a.N, nw);
+  int64_t capb = (int64_t)a.ctx->num_cu * per_cu;
+  const int64_t slab_cap = ((int64_t)64 << 20) / ((int64_t)2 * L * (int64_t)sizeof(double));   // slabs <= 64 MiB
+  if (a.estats && capb > slab_cap) capb = slab_cap > 0 ? slab_cap : 1;
   if (nb > capb) nb = capb;
-  const size_t lds = a.estats ? (size_t)Lp * 8 : 0;
-  BNPVI_REQUIRE(lds <= (size_t)kMaxLdsBytes, "estep: L=%d too large for the stats epilogue", L);
+  double* eslab = nullptr;
+  if (a.estats) {
+    int rc = a.ctx->slabs.ensure((size_t)nb * 2 * L * sizeof(double));
+    if (rc) return rc;
+    eslab = (double*)a.ctx->slabs.ptr;
+  }
   if (a.mode == BNPVI_ESTEP_HARD) {
     auto k = estep_normalize_kernel<true>;
     if (lds > 48 * 1024)
       BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, a.stream, a.phi, a.logphi, a.assign, part,
-                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, a.estats);
+    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(64 * nw), lds, a.stream, a.phi, a.logphi, a.assign, part,
+                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, eslab);
   } else {
     auto k = estep_normalize_kernel<false>;
     if (lds > 48 * 1024)
       BNPVI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(256), lds, a.stream, a.phi, a.logphi, a.assign, part,
-                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, a.estats);
+    hipLaunchKernelGGL(k, dim3((unsigned)nb), dim3(64 * nw), lds, a.stream, a.phi, a.logphi, a.assign, part,
+                       nchunk, a.prior, a.vid, a.N, L, Lp, 1.f / a.half_sz, eslab);
   }
   BNPVI_LAUNCH_CHECK();
+  if (a.estats) return estep_reduce_slabs(a, eslab, (int)nb);
   return BNPVI_OK;
 }
 
