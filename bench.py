@@ -387,6 +387,14 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
         group = dist.group.WORLD
+    elif os.environ.get("BNPVI_DIST_FORCE_COLLECTIVES") == "1":
+        # measurement aid for the N > 1 budget: ONE rank in an RCCL group, every collective of the step
+        # issued anyway (bnp_vae_amd/dist.py) -- what the two all-reduces cost a step before any link time
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        group = dist.group.WORLD
+        backend = "nccl (one rank, collectives forced)"
 
     run = Runner(torch, dist, device, local_rank, rank, world, group, rehearsal)
     want_estats = not args.no_estats
@@ -442,7 +450,7 @@ def main():
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if group is not None:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,8 @@ of an iteration is one all-reduce (sum, fp64) of the per-leaf statistics [S0 | S
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -17,6 +19,16 @@ def world_size(group):
         return 1
     import torch.distributed as dist
     return dist.get_world_size(group)
+
+
+def is_distributed(group):
+    """True when the collectives below must run: more than one rank -- or a group of ONE rank under
+    BNPVI_DIST_FORCE_COLLECTIVES=1, the switch with which a one-GPU box runs every collective of the path through
+    RCCL itself (tests/test_gpu_round3.py::test_rccl_collectives_on_a_single_rank_group); sums, gathers and
+    broadcasts over one rank leave the results unchanged."""
+    if group is None:
+        return False
+    return world_size(group) > 1 or os.environ.get("BNPVI_DIST_FORCE_COLLECTIVES") == "1"
 
 
 def shard_videos(frames_per_video, world):
@@ -54,7 +66,7 @@ def _host_staged(group):
 
 def allreduce_sum_(t, group):
     """In-place sum over ranks (the single per-iteration collective on the statistics buffer)."""
-    if world_size(group) > 1:
+    if is_distributed(group):
         import torch.distributed as dist
         if t.is_cuda and _host_staged(group):
             h = t.cpu()
@@ -67,7 +79,7 @@ def allreduce_sum_(t, group):
 
 def global_count(n_local, group, device):
     """(sum of n_local over ranks, exclusive prefix = global index of this rank's first frame)."""
-    if world_size(group) == 1:
+    if not is_distributed(group):
         return int(n_local), 0
     import torch
     import torch.distributed as dist
@@ -84,7 +96,7 @@ def select_argmax(score, global_row, group, device):
     """Arg-max over ranks of (score, global row): the highest score wins, the LOWEST global row
     wins ties (np.argmax semantics of src/var_inf.py:30,35).  A rank without frames passes
     score = -1.  Returns (winning global row, rank that owns it)."""
-    if world_size(group) == 1:
+    if not is_distributed(group):
         return int(global_row), 0
     import torch
     import torch.distributed as dist
@@ -104,7 +116,7 @@ def select_argmax_many(scores, global_rows, group):
     of this rank's winners.  Returns (winning global rows [J] int64, mask [J] of the columns this rank owns)
     on the tensors' device -- one all-gather of a [J, 2] table."""
     import torch
-    if world_size(group) == 1:
+    if not is_distributed(group):
         return global_rows, torch.ones_like(global_rows, dtype=torch.bool)
     import torch.distributed as dist
     me = dist.get_rank(group)
@@ -124,7 +136,7 @@ def select_argmax_many(scores, global_rows, group):
 
 def broadcast_from(t, owner, group):
     """Broadcast `t` from group rank `owner` (the chosen k-means centre row)."""
-    if world_size(group) > 1:
+    if is_distributed(group):
         import torch.distributed as dist
         src = dist.get_global_rank(group, owner)
         if t.is_cuda and _host_staged(group):

@@ -364,7 +364,7 @@ class DeviceVI(object):
                 rows.extend(r)
                 cen.extend(c)
             return rows, np.asarray(cen)
-        multi = vdist.world_size(self.group) > 1
+        multi = vdist.is_distributed(self.group)
         cols_t = torch.as_tensor(np.asarray(cols, dtype=np.int32), device=self.device)
         best_row = torch.zeros((J,), dtype=torch.int64, device=self.device)
         best_score = torch.full((J,), -1.0, dtype=torch.float64, device=self.device)

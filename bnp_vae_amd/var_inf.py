@@ -101,10 +101,8 @@ class VarInf(object):
         return self._dev
 
     def _multi(self):
-        if self._group is None:
-            return False
-        import torch.distributed as dist
-        return dist.get_world_size(self._group) > 1
+        from . import dist as vdist
+        return vdist.is_distributed(self._group)
 
     def _num_frames_global(self):
         n = len(self.vidid_frameid_to_idx)

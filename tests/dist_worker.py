@@ -119,8 +119,18 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
+    backend = os.environ.get("BNPVI_WORKER_BACKEND", "gloo")       # "nccl" (= RCCL): one rank per device only
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = {"all_reduce": 0, "all_gather": 0, "broadcast": 0}
+    for name in calls:                                            # count what the path really sends
+        def counted(*a, _f=getattr(dist, name), _n=name, **kw):
+            calls[_n] += 1
+            return _f(*a, **kw)
+        setattr(dist, name, counted)
     from bnp_vae_amd import VarInf
     from bnp_vae_amd import dist as vdist
     from oracle.vi_oracle import snapshot, drifting_latents
@@ -157,6 +167,9 @@ def main():
         for k in ("ids", "parent", "is_leaf", "alpha", "sigma", "gamma", "phi", "decay"):
             out["e%d_%s" % (ep, k)] = snap[k]
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+    if rank == 0:
+        print("collectives run: all_reduce=%d all_gather=%d broadcast=%d backend %s" % (
+            calls["all_reduce"], calls["all_gather"], calls["broadcast"], dist.get_backend()), flush=True)
     leave(dist)
 
 

@@ -272,6 +272,33 @@ def test_multi_rank_trajectory_matches_single_rank_golden(golden, world, tmp_pat
                                port, str(tmp_path), golden], cwd=root) for r in range(world)]
     codes = [p.wait(timeout=600) for p in procs]
     assert codes == [0] * world
+    _ranks_hold_the_golden(g, m, tmp_path, world)
+
+
+def test_rccl_collectives_on_a_single_rank_group(tmp_path):
+    """The RCCL branch of bnp_vae_amd/dist.py on the hardware this suite has: ONE rank, process group "nccl"
+    (= RCCL), BNPVI_DIST_FORCE_COLLECTIVES=1 so that the group of one still runs every collective of the path on
+    DEVICE tensors -- the fp64 all-reduces of the leaf and split/merge statistics and of the centre table, the
+    all-gathers of the frame count and of the [J, 2] arg-max table, the broadcast of the initial means -- in the
+    stream order the multi-GPU run has.  Sums and gathers over one rank change nothing, so the rank must hold the
+    single-rank golden.  (More than one rank needs more than one GPU: two ranks cannot share a device under RCCL.)"""
+    import subprocess
+    import sys
+    golden = "traj_dynamic.npz"
+    g = load(golden)
+    m = meta(g)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BNPVI_WORKER_BACKEND="nccl", BNPVI_DIST_FORCE_COLLECTIVES="1")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_worker.py"), "0", "1", str(_free_port()),
+                        str(tmp_path), golden], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert "collectives run: " in p.stdout and "backend nccl" in p.stdout, p.stdout[-2000:]
+    counts = dict(kv.split("=") for kv in p.stdout.split("collectives run: ")[1].split()[:3])
+    assert int(counts["all_reduce"]) >= 2 * m['epochs'] and int(counts["all_gather"]) >= 1 and int(counts["broadcast"]) >= 1
+    _ranks_hold_the_golden(g, m, tmp_path, 1)
+
+
+def _ranks_hold_the_golden(g, m, tmp_path, world):
     N = None
     for r in range(world):
         got = dict(np.load(str(tmp_path / ("rank%d.npz" % r)), allow_pickle=False))
