@@ -7,6 +7,7 @@
 // All of this is fp64 (the reference is NumPy fp64) except where noted; none of it is on the
 // N*L*D critical path, so the kernels favour exactness and simplicity.
 #include <math.h>
+#include <string.h>
 
 #include "common.h"
 #include "estep_kernels.h"
@@ -961,15 +962,45 @@ struct NestTree {
   int K, L, internal_levels;
 };
 
+// LDS_TREE: the tree's index arrays are copied into LDS once per workgroup (L + 4K + levels ints behind the four
+// node images).  Read from global memory they put three or four dependent L2 round trips into every level of every
+// dominated row: 2.15 ms per 2M frames at K = 80, against 0.72 ms for the flat rule this kernel replaced.
+__host__ __device__ inline size_t nest_tree_ints(int K, int L, int internal_levels) {
+  return (size_t)L + 4 * (size_t)K + 1 + (size_t)internal_levels + 1;
+}
+
+template <bool LDS_TREE>
 __global__ __launch_bounds__(256) void kmeans_first_nested_kernel(const float* __restrict__ phi, int ldphi, int64_t N,
-                                                                  NestTree t, const int32_t* __restrict__ cols, int J,
+                                                                  NestTree tg, const int32_t* __restrict__ cols, int J,
                                                                   Best* __restrict__ part32,
                                                                   Best64* __restrict__ part64) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ Best sh32[4][64];
   __shared__ Best64 sh64[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* val = reinterpret_cast<double*>(smem_raw) + (size_t)wave * t.K;     // this wave's image of the nodes
+  double* val = reinterpret_cast<double*>(smem_raw) + (size_t)wave * tg.K;    // this wave's image of the nodes
+  NestTree t = tg;
+  if (LDS_TREE) {
+    int32_t* base = reinterpret_cast<int32_t*>(reinterpret_cast<double*>(smem_raw) + (size_t)4 * tg.K);
+    int32_t* nol = base;
+    int32_t* lofn = nol + tg.L;
+    int32_t* cptr = lofn + tg.K;
+    int32_t* cidx = cptr + tg.K + 1;
+    int32_t* lnodes = cidx + tg.K;
+    int32_t* lptr = lnodes + tg.K;
+    for (int i = threadIdx.x; i < tg.L; i += 256) nol[i] = tg.node_of_leaf[i];
+    for (int i = threadIdx.x; i < tg.K; i += 256) {
+      lofn[i] = tg.leaf_of_node[i];
+      cptr[i] = tg.child_ptr[i];
+      cidx[i] = i < tg.K - 1 ? tg.child_idx[i] : 0;                           // K - 1 edges
+      lnodes[i] = tg.level_nodes[i];
+    }
+    if (threadIdx.x == 0) cptr[tg.K] = tg.child_ptr[tg.K];
+    for (int i = threadIdx.x; i <= tg.internal_levels; i += 256) lptr[i] = tg.level_ptr[i];
+    __syncthreads();
+    t.node_of_leaf = nol; t.leaf_of_node = lofn; t.child_ptr = cptr; t.child_idx = cidx;
+    t.level_nodes = lnodes; t.level_ptr = lptr;
+  }
   const int mycol = lane < J ? cols[lane] : 0;
   Best b32;
   b32.score = -1.f;
@@ -990,6 +1021,18 @@ __global__ __launch_bounds__(256) void kmeans_first_nested_kernel(const float* _
       mask &= mask - 1ull;
       const int col = __builtin_amdgcn_readlane(mycol, jl);
       const double pc = (double)__uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(wn), jl));
+      // Screen: a wave meets its rows in ascending order, so a row only matters if it BEATS the column's best so far.
+      // 1 / phi_sum <= 1, and it equals 1 / (1 + c / pc), c = the other leaves' mass, up to the nest's rounding
+      // (a few 2^-53) and the fp32 sum's (< 64 * 2^-24 of c): rows that cannot reach the best skip the nest.
+      {
+        float part = 0.f;
+        for (int l = lane; l < t.L; l += 64) part += l == col ? 0.f : row[l];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) part += __shfl_xor(part, off);
+        const double rest = (double)part / pc;
+        const double bestj = __shfl(b64.score, jl);
+        if (bestj >= 1.0 || 1.0 / (1.0 + rest) + 1e-5 * rest + 1e-12 < bestj) continue;
+      }
       for (int l = lane; l < t.L; l += 64) val[t.node_of_leaf[l]] = l == col ? 1.0 : (double)row[l] / pc;
       wave_sync_lds();
       for (int lev = t.internal_levels - 1; lev >= 0; --lev) {
@@ -1031,8 +1074,11 @@ constexpr size_t kNestLdsMax = 96 * 1024;      // 4 waves x K doubles: trees of 
 
 int launch_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* t, const float* phi, int ldphi, int64_t N,
                                const int32_t* cols, int J, int64_t* best_row, double* best_score, hipStream_t s) {
-  const size_t lds = (size_t)4 * t->K * sizeof(double);
+  size_t lds = (size_t)4 * t->K * sizeof(double);
   if (lds > kNestLdsMax) return BNPVI_EUNSUPPORTED;
+  const size_t with_tree = lds + nest_tree_ints(t->K, t->L, t->internal_levels) * sizeof(int32_t);
+  const bool lds_tree = with_tree <= (size_t)kMaxLdsBytes - 16384;           // room for the kernel's static tables (8 KB)
+  if (lds_tree) lds = with_tree;
   int64_t blocks = ceil_div(N, (int64_t)4);
   const int64_t cap = (int64_t)ctx->num_cu * 8;
   if (blocks > cap) blocks = cap;
@@ -1042,11 +1088,10 @@ int launch_kmeans_first_nested(bnpvi_ctx* ctx, const bnpvi_tree* t, const float*
   Best* p32 = (Best*)(p64 + blocks * J);
   NestTree nt{t->d_node_of_leaf, t->d_leaf_of_node, t->d_child_ptr, t->d_child_idx, t->d_level_ptr, t->d_level_nodes,
               t->K, t->L, t->internal_levels};
+  auto kern = lds_tree ? kmeans_first_nested_kernel<true> : kmeans_first_nested_kernel<false>;
   if (lds > 48 * 1024)
-    BNPVI_HIP(hipFuncSetAttribute((const void*)kmeans_first_nested_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-  hipLaunchKernelGGL(kmeans_first_nested_kernel, dim3((unsigned)blocks), dim3(256), lds, s, phi, ldphi, N, nt, cols, J,
-                     p32, p64);
+    BNPVI_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, phi, ldphi, N, nt, cols, J, p32, p64);
   BNPVI_LAUNCH_CHECK();
   hipLaunchKernelGGL(kmeans_final_multi_kernel, dim3(J), dim3(256), 0, s, p32, p64, (int)blocks, J, best_row,
                      best_score);
@@ -1128,6 +1173,87 @@ __global__ __launch_bounds__(256) void kmeans_pass_multi_kernel(const float* __r
   if ((int)threadIdx.x < J) partial[(int64_t)blockIdx.x * J + threadIdx.x] = sh[threadIdx.x];
 }
 
+// The same pass with ONE LANE PER ROW (Dp <= 128).  The kernel above spends more on adding a row's partial sums
+// across its G lanes (a five-step butterfly per row and centre) than on the differences themselves: 0.87 ms per
+// 2M x 128 frames and 24 columns.  Here a lane keeps its whole row in registers, the centres are wave-uniform
+// (scalar loads), the squared differences run down the row in eight independent fp32 chains added pairwise at the
+// end, and nothing crosses lanes until the wave's arg-max per column (one butterfly per column and 64 rows).
+// A wave's running best per column lives in LDS (no register array indexed by a runtime j).
+template <int DP>
+__global__ __launch_bounds__(256) void kmeans_pass_rows_kernel(const float* __restrict__ Z, int ldz, int64_t N,
+                                                               const float* __restrict__ phi, int ldphi,
+                                                               const int32_t* __restrict__ cols, int J,
+                                                               const float* __restrict__ centres, int first,
+                                                               float* __restrict__ dist2,
+                                                               Best* __restrict__ partial) {
+  __shared__ Best sh[4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (lane < J) {
+    sh[wave][lane].score = -1.f;
+    sh[wave][lane].row = 0x7fffffffffffffffLL;
+  }
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wave) * 64; base < N; base += (int64_t)gridDim.x * 256) {
+    const int64_t n = base + lane;
+    const bool ok = n < N;
+    const int64_t nr = ok ? n : N - 1;
+    float z[DP];
+    {
+      const float4* zr = reinterpret_cast<const float4*>(Z + nr * ldz);
+#pragma unroll
+      for (int q = 0; q < DP / 4; ++q) {
+        const float4 v = zr[q];
+        z[4 * q] = v.x;
+        z[4 * q + 1] = v.y;
+        z[4 * q + 2] = v.z;
+        z[4 * q + 3] = v.w;
+      }
+    }
+    const float* prow = phi + nr * ldphi;
+    float* drow = dist2 + nr * J;
+    for (int j = 0; j < J; ++j) {                                 // wave-uniform
+      const float* c = centres + (int64_t)j * DP;
+      float acc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int d = 0; d < DP; ++d) {
+        const float df = z[d] - c[d];
+        acc[d & 7] = fmaf(df, df, acc[d & 7]);
+      }
+      const float myd = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      const float wn = prow[cols[j]];
+      const float dm = first ? myd : fminf(drow[j], myd);
+      if (ok) drow[j] = dm;
+      float score = ok ? wn * __builtin_amdgcn_sqrtf(dm) : -1.f;
+      long long row = ok ? n : 0x7fffffffffffffffLL;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float os = __shfl_xor(score, off);
+        const long long orow = __shfl_xor(row, off);
+        if (better(os, orow, score, row)) {
+          score = os;
+          row = orow;
+        }
+      }
+      if (lane == 0 && better(score, row, sh[wave][j].score, sh[wave][j].row)) {
+        sh[wave][j].score = score;
+        sh[wave][j].row = row;
+      }
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < J) {
+    Best b = sh[0][threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const Best o = sh[w][threadIdx.x];
+      if (better(o.score, o.row, b.score, b.row)) b = o;
+    }
+    partial[(int64_t)blockIdx.x * J + threadIdx.x] = b;
+  }
+}
+
 int launch_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N, int D, const float* phi,
                              int ldphi, int L, const int32_t* cols, int J, const float* centres, int first,
                              float* dist2, int64_t* best_row, double* best_score, hipStream_t s) {
@@ -1150,13 +1276,31 @@ int launch_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N,
     BNPVI_LAUNCH_CHECK();
     return BNPVI_OK;
   }
-  const int64_t rows_per_block = 256 / G;
+  const char* kenv = dev_getenv("BNPVI_KMEANS_PASS");                  // development switch: "groups" = the kernel above
+  const bool by_rows = Dp <= 128 && (((uintptr_t)Z) & 15) == 0 && ldz % 4 == 0 && !(kenv && strcmp(kenv, "groups") == 0);
+  const int64_t rows_per_block = by_rows ? 256 : 256 / G;
   blocks = ceil_div(N, rows_per_block);
   const int64_t cap = (int64_t)ctx->num_cu * 8;
   if (blocks > cap) blocks = cap;
   int rc = ctx->red.ensure((size_t)blocks * J * sizeof(Best));
   if (rc) return rc;
   Best* part = (Best*)ctx->red.ptr;
+  if (by_rows) {
+#define KMR(DD)                                                                                              \
+  hipLaunchKernelGGL(kmeans_pass_rows_kernel<DD>, dim3((unsigned)blocks), dim3(256), 0, s, Z, ldz, N, phi, ldphi, \
+                     cols, J, centres, first, dist2, part)
+    switch (Dp) {
+      case 32: KMR(32); break;
+      case 64: KMR(64); break;
+      default: KMR(128); break;
+    }
+#undef KMR
+    BNPVI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kmeans_final_multi_kernel, dim3(J), dim3(256), 0, s, part, (const Best64*)nullptr,
+                       (int)blocks, J, best_row, best_score);
+    BNPVI_LAUNCH_CHECK();
+    return BNPVI_OK;
+  }
 #define KMM(GG)                                                                                          \
   hipLaunchKernelGGL(kmeans_pass_multi_kernel<GG>, dim3((unsigned)blocks), dim3(256), 0, s, Z, ldz, N, phi, \
                      ldphi, cols, J, centres, first, dist2, part)
@@ -1177,16 +1321,48 @@ int launch_kmeans_pass_multi(bnpvi_ctx* ctx, const float* Z, int ldz, int64_t N,
 // ------------------------------------------------------------------------------------------
 // out[n][j] = scale[j] * in[n][src[j]]  (split: phi_parent/num_splits; merge: drop columns)
 // ------------------------------------------------------------------------------------------
-__global__ void remap_columns_kernel(const float* __restrict__ in, int ld_in, float* __restrict__ out,
-                                     int ld_out, int64_t N, const int32_t* __restrict__ src,
-                                     const float* __restrict__ scale) {
-  const int64_t total = N * ld_out;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = e / ld_out;
-    const int j = (int)(e % ld_out);
-    const int sj = src[j];
-    out[e] = sj >= 0 ? scale[j] * in[n * ld_in + sj] : 0.f;
+// A thread owns FOUR consecutive output columns (one 16-byte store per row) and walks rows: no per-element
+// division, the columns' sources and scales stay in registers when a row has at most 256 quads.  (The first
+// version -- one element per thread, a 64-bit division each -- ran at 1.2 TB/s: 1.3 ms per 2M x 96 matrix.)
+__global__ __launch_bounds__(256) void remap_columns_kernel(const float* __restrict__ in, int ld_in,
+                                                            float* __restrict__ out, int ld_out, int64_t N,
+                                                            const int32_t* __restrict__ src,
+                                                            const float* __restrict__ scale) {
+  const int Q = ld_out >> 2;                       // ld_out is a multiple of 4 (checked by the launcher)
+  if (Q <= 256) {
+    const int rpb = 256 / Q;                       // rows per workgroup and trip
+    const int rl = (int)threadIdx.x / Q, q = (int)threadIdx.x % Q;
+    if (rl >= rpb) return;
+    int sj[4];
+    float sc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      sj[c] = src[4 * q + c];
+      sc[c] = scale[4 * q + c];
+    }
+    for (int64_t n = (int64_t)blockIdx.x * rpb + rl; n < N; n += (int64_t)gridDim.x * rpb) {
+      const float* row = in + n * ld_in;
+      float4 v;
+      v.x = sj[0] >= 0 ? sc[0] * row[sj[0]] : 0.f;
+      v.y = sj[1] >= 0 ? sc[1] * row[sj[1]] : 0.f;
+      v.z = sj[2] >= 0 ? sc[2] * row[sj[2]] : 0.f;
+      v.w = sj[3] >= 0 ? sc[3] * row[sj[3]] : 0.f;
+      *reinterpret_cast<float4*>(out + n * ld_out + 4 * q) = v;
+    }
+    return;
+  }
+  for (int64_t n = blockIdx.x; n < N; n += gridDim.x) {
+    const float* row = in + n * ld_in;
+    for (int q = threadIdx.x; q < Q; q += 256) {
+      const int4 s4 = *reinterpret_cast<const int4*>(src + 4 * q);
+      const float4 c4 = *reinterpret_cast<const float4*>(scale + 4 * q);
+      float4 v;
+      v.x = s4.x >= 0 ? c4.x * row[s4.x] : 0.f;
+      v.y = s4.y >= 0 ? c4.y * row[s4.y] : 0.f;
+      v.z = s4.z >= 0 ? c4.z * row[s4.z] : 0.f;
+      v.w = s4.w >= 0 ? c4.w * row[s4.w] : 0.f;
+      *reinterpret_cast<float4*>(out + n * ld_out + 4 * q) = v;
+    }
   }
 }
 
@@ -1208,8 +1384,9 @@ int launch_remap_columns(bnpvi_ctx* ctx, const float* in, int ld_in, float* out,
   BNPVI_HIP(hipMemcpyAsync(dscale, scale.data(), (size_t)ld_out * 4, hipMemcpyHostToDevice, s));
   BNPVI_HIP(hipStreamSynchronize(s));
   if (N == 0) return BNPVI_OK;
-  int64_t blocks = ceil_div(N * ld_out, 256);
-  const int64_t cap = (int64_t)ctx->num_cu * 16;
+  const int Q = ld_out / 4;
+  int64_t blocks = Q <= 256 ? ceil_div(N, (int64_t)(256 / Q)) : N;
+  const int64_t cap = (int64_t)ctx->num_cu * 8;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(remap_columns_kernel, dim3((unsigned)blocks), dim3(256), 0, s, in, ld_in, out,
                      ld_out, N, dsrc, dscale);
