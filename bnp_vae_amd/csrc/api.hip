@@ -97,14 +97,6 @@ void KernelTimer::release() {
   used = 0;
 }
 
-template <typename T>
-static int upload(const std::vector<T>& h, T** d) {
-  size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
-  BNPVI_HIP(hipMalloc((void**)d, bytes));
-  if (!h.empty()) BNPVI_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return BNPVI_OK;
-}
-
 }  // namespace bnpvi
 
 using namespace bnpvi;
@@ -271,27 +263,39 @@ int bnpvi_tree_create(bnpvi_ctx* ctx, int K, const int32_t* parent, const uint8_
   for (int k = 0; k < K; ++k)
     if (t->leaf_of_node[k] < 0 && t->depth[k] + 1 > t->internal_levels) t->internal_levels = t->depth[k] + 1;
   BNPVI_HIP(hipSetDevice(ctx->device));
-  int rc = BNPVI_OK;
-  if ((rc = upload(t->parent, &t->d_parent)) || (rc = upload(t->depth, &t->d_depth)) ||
-      (rc = upload(t->leaf_of_node, &t->d_leaf_of_node)) ||
-      (rc = upload(t->node_of_leaf, &t->d_node_of_leaf)) ||
-      (rc = upload(t->leaf_lo, &t->d_leaf_lo)) || (rc = upload(t->leaf_hi, &t->d_leaf_hi)) ||
-      (rc = upload(t->child_ptr, &t->d_child_ptr)) || (rc = upload(t->child_idx, &t->d_child_idx)) ||
-      (rc = upload(t->level_nodes, &t->d_level_nodes)) ||
-      (rc = upload(t->level_ptr, &t->d_level_ptr))) {
-    bnpvi_tree_destroy(t);
-    return rc;
+  // One allocation and one copy for the ten index arrays (a tree is rebuilt after every split / merge walk: ten
+  // allocations, ten blocking copies and, at destruction, ten hipFree -- each a device-wide wait -- were ~0.3 ms of
+  // such a call).  Every array starts on a 64-byte boundary.
+  const std::vector<int32_t>* src[10] = {&t->parent, &t->depth, &t->leaf_of_node, &t->node_of_leaf, &t->leaf_lo,
+                                         &t->leaf_hi, &t->child_ptr, &t->child_idx, &t->level_nodes, &t->level_ptr};
+  int32_t** dst[10] = {&t->d_parent, &t->d_depth, &t->d_leaf_of_node, &t->d_node_of_leaf, &t->d_leaf_lo,
+                       &t->d_leaf_hi, &t->d_child_ptr, &t->d_child_idx, &t->d_level_nodes, &t->d_level_ptr};
+  size_t off[10], total = 0;
+  for (int a = 0; a < 10; ++a) {
+    off[a] = total;
+    total += (src[a]->size() + 15) / 16 * 16 + 16;     // never empty: every array keeps its own address
   }
+  std::vector<int32_t> host(total, 0);
+  for (int a = 0; a < 10; ++a)
+    if (!src[a]->empty()) memcpy(host.data() + off[a], src[a]->data(), src[a]->size() * sizeof(int32_t));
+  if (hipMalloc((void**)&t->d_block, total * sizeof(int32_t)) != hipSuccess) {
+    set_error("bnpvi_tree_create: hipMalloc(%zu) failed", total * sizeof(int32_t));
+    delete t;
+    return BNPVI_ENOMEM;
+  }
+  if (hipMemcpy(t->d_block, host.data(), total * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("bnpvi_tree_create: upload of the index arrays failed");
+    bnpvi_tree_destroy(t);
+    return BNPVI_EHIP;
+  }
+  for (int a = 0; a < 10; ++a) *dst[a] = t->d_block + off[a];
   *out = t;
   return BNPVI_OK;
 }
 
 int bnpvi_tree_destroy(bnpvi_tree* t) {
   if (!t) return BNPVI_OK;
-  void* ptrs[] = {t->d_parent,  t->d_depth,     t->d_leaf_of_node, t->d_node_of_leaf, t->d_leaf_lo,
-                  t->d_leaf_hi, t->d_child_ptr, t->d_child_idx,    t->d_level_nodes, t->d_level_ptr};
-  for (void* p : ptrs)
-    if (p) (void)hipFree(p);
+  if (t->d_block) (void)hipFree(t->d_block);
   delete t;
   return BNPVI_OK;
 }

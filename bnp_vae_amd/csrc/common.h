@@ -125,6 +125,7 @@ struct bnpvi_tree {
           *d_node_of_leaf = nullptr, *d_leaf_lo = nullptr, *d_leaf_hi = nullptr,
           *d_child_ptr = nullptr, *d_child_idx = nullptr, *d_level_nodes = nullptr,
           *d_level_ptr = nullptr;
+  int32_t* d_block = nullptr;   // the ONE allocation all device copies live in (uploaded with one copy)
 };
 
 // kernels' launchers (one per .hip file)
