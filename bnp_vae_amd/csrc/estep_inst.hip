@@ -278,6 +278,16 @@ int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   const bool want_rows = force ? strcmp(force, "rows") == 0 : Lp > 64;
   if (Lp > 64 && !force && rows1_fits<DP>(a))
     return run_rows1<DP, Rows1Lds<DP>::max_chunks()>(a, (int)ceil_div(Lp, kLT * kRChunk));
+  // 65 .. 128 padded leaves with S2 wanted in the kernel (the engine asks for it up to 100 leaves): the fused kernel
+  // with eight leaf tiles keeps a frame's whole row of logits in registers, the two-pass row kernel computes every
+  // product twice -- 2M frames, L = 81 / 100 / 121: D = 128 569 / 649 / 672 us against 1120 / 1230 / 1230,
+  // D = 64 354 / 392 / 408 against 543 / 556 / 574 (tools/dev/g28.sh).  (S0-only and no statistics stay on the one-pass
+  // row kernel above, which is faster still; log phi / arg-max requests and hard mode stay where they were.)
+  if constexpr (DP <= 128) {
+    if (!force && Lp > 64 && Lp <= 128 && a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr && a.logphi == nullptr &&
+        a.estats != nullptr && fused_lds_bytes<DP, 8>() <= (size_t)kMaxLdsBytes)
+      return run_fused<DP, 8>(a);
+  }
   if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
     return a.estats ? run_rows<DP, true>(a) : run_rows<DP, false>(a);
   if (!hard_stats) {
