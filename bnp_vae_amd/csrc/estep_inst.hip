@@ -283,11 +283,10 @@ int estep_dispatch<BNPVI_DP>(const EstepArgs& a) {
   // product twice -- 2M frames, L = 81 / 100 / 121: D = 128 569 / 649 / 672 us against 1120 / 1230 / 1230,
   // D = 64 354 / 392 / 408 against 543 / 556 / 574 (tools/dev/g28.sh).  (S0-only and no statistics stay on the one-pass
   // row kernel above, which is faster still; log phi / arg-max requests and hard mode stay where they were.)
-  if constexpr (DP <= 128) {
-    if (!force && Lp > 64 && Lp <= 128 && a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr && a.logphi == nullptr &&
-        a.estats != nullptr && fused_lds_bytes<DP, 8>() <= (size_t)kMaxLdsBytes)
-      return run_fused<DP, 8>(a);
-  }
+  // D = 256 (1M frames, L = 81): 1111 us against 2199.
+  if (!force && Lp > 64 && Lp <= 128 && a.mode == BNPVI_ESTEP_SOFT && a.assign == nullptr && a.logphi == nullptr &&
+      a.estats != nullptr && fused_lds_bytes<DP, 8>() <= (size_t)kMaxLdsBytes)
+    return run_fused<DP, 8>(a);
   if (want_rows && !(force && strcmp(force, "fused") == 0) && rows_fits<DP>(a))
     return a.estats ? run_rows<DP, true>(a) : run_rows<DP, false>(a);
   if (!hard_stats) {

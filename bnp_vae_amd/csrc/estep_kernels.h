@@ -598,7 +598,7 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
 #endif
 // waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane)
 constexpr int fused_min_waves(int DP, int NT) {
-  return (NT <= 4 && DP <= 64) ? BNPVI_FUSED_MINW_SMALL : (NT <= 8 && DP <= 128) ? 2 : 1;
+  return (NT <= 4 && DP <= 64) ? BNPVI_FUSED_MINW_SMALL : (NT <= 8 && DP <= 128) ? 2 : (NT <= 4) ? 2 : 1;
 }
 
 template <int DP, int NT, int PF, bool HARD, bool STATS>
