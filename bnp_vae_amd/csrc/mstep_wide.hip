@@ -570,6 +570,9 @@ static int run_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, i
   return launch_slab_reduce(slab_ws, (int)gx, (int64_t)L * W, stats, s);
 }
 
+// padded leaves from which the workgroup-wide tiles take over from the per-wave ring, by padded latent dim
+constexpr int kWideFrom256 = 160, kWideFrom128 = 320, kWideFrom64 = 384;
+
 int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float* phi, int ldphi,
                            const int32_t* vid, int64_t N, int D, int L, int V, double* stats, double* mass,
                            hipStream_t s) {
@@ -585,15 +588,20 @@ int launch_leaf_stats_wide(bnpvi_ctx* ctx, const float* Z, int ldz, const float*
   const char* env = dev_getenv("BNPVI_WIDE_F16");                       // development switch: "off" / "on"
   const bool can16 = ctx->small != nullptr && (((uintptr_t)Z) & 15) == 0;
   const bool f16 = can16 && (env ? strcmp(env, "off") != 0 : ((int64_t)ldphi * ldz >= kWideF16From));
-  if (ldz % 256 == 0 && ldphi >= 256 && f16)
+  // A workgroup tile need not be full: columns past the padded leaves re-read a valid column and are dropped at the
+  // output, so a tile costs the same whatever part of it the tree fills, while the ring's time grows with the
+  // leaves.  From the regime sweep (1M frames; ring at L = 144 / 196 / 400 against ONE wide tile): D = 256 896 /
+  // 1166 us against ~700; D = 128 1105 us (L = 400) against 750; D = 64 625 us (L = 400) against 534.
+  const int from256 = kWideFrom256, from128 = kWideFrom128, from64 = kWideFrom64;
+  if (ldz % 256 == 0 && ldphi >= from256 && f16)
     return run_wide<2, 2, 4, 4, true>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  if (ldz % 256 == 0 && ldphi >= 256)
+  if (ldz % 256 == 0 && ldphi >= from256)
     return run_wide<2, 2, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  if (ldz % 128 == 0 && ldphi >= 512 && f16)
+  if (ldz % 128 == 0 && ldz % 256 != 0 && ldphi >= from128 && f16)
     return run_wide<4, 1, 4, 4, true>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  if (ldz % 128 == 0 && ldphi >= 512)
+  if (ldz % 128 == 0 && ldz % 256 != 0 && ldphi >= from128)
     return run_wide<4, 1, 4, 4>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
-  if (ldz == 64 && ldphi >= 512) return run_wide<4, 1, 4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
+  if (ldz == 64 && ldphi >= from64) return run_wide<4, 1, 4, 2>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, stats, mass, s);
   return BNPVI_EUNSUPPORTED;
 }
 
