@@ -372,6 +372,15 @@ int launch_leaf_stats_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* 
   const bool l2 = tilesL % 2 == 0, d2 = tilesD % 2 == 0;
 #define RUN(TL, TD) \
   return run_dma<TL, TD, R>(ctx, Z, ldz, phi, ldphi, vid, N, D, L, W, tilesL, tilesD, stats, mass, s)
+  // four dim tiles per wave where the padded dims allow (D = 128, 256): phi is then read once per 128 dims instead
+  // of once per 64
+  // (2M frames, 64 x 64 tiles -> 64 x 128: D = 128 L = 64 / 121 / 256 370 -> 343, 634 -> 570, 1141 -> 1010 us;
+  //  D = 256 L = 64 / 121 670 -> 615, 1186 -> 1033 us; a third ring slot on top: no change)
+  const char* td4 = dev_getenv("BNPVI_DMA_TD4");                        // development switch: "0" = 64-dim tiles
+  if (tilesD % 4 == 0 && !(td4 && td4[0] == '0')) {
+    if (l2) RUN(2, 4);
+    RUN(1, 4);
+  }
   if (l2 && d2) RUN(2, 2);
   if (l2) RUN(2, 1);
   if (d2) RUN(1, 2);
