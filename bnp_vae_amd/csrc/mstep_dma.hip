@@ -381,6 +381,8 @@ int launch_leaf_stats_dma(bnpvi_ctx* ctx, const float* Z, int ldz, const float* 
     if (l2) RUN(2, 4);
     RUN(1, 4);
   }
+  const char* tl4 = dev_getenv("BNPVI_DMA_TL4");                        // development switch: "0" = 64-leaf tiles
+  if (tilesL % 4 == 0 && tilesD == 2 && !(tl4 && tl4[0] == '0')) RUN(4, 2);   // D = 64: Z read once per 128 leaves
   if (l2 && d2) RUN(2, 2);
   if (l2) RUN(2, 1);
   if (d2) RUN(1, 2);
