@@ -593,12 +593,17 @@ __device__ __forceinline__ void fused_tile(const FusedParams& p, const LeafOpera
     tile_epilogue_soft<NT, TV, STATS>(p, n, ok, lane, tiles_valid, prow, pre, d2, s0, s2);
 }
 
+#ifndef BNPVI_FUSED_MINW3_DP
+#define BNPVI_FUSED_MINW3_DP 128
+#endif
 #ifndef BNPVI_FUSED_MINW_SMALL
 #define BNPVI_FUSED_MINW_SMALL 3
 #endif
-// waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane)
+// waves per SIMD the fused kernel is compiled for (register budget 512 / that many per lane).  Up to four leaf tiles
+// three waves also at D = 128 (round 3: with statistics the kernel took 201 registers and ran two; at 168 it keeps
+// 11 dwords in scratch and is 13 % faster, 428 -> 374 us per 2M frames at L = 64) and two at D = 256.
 constexpr int fused_min_waves(int DP, int NT) {
-  return (NT <= 4 && DP <= 64) ? BNPVI_FUSED_MINW_SMALL : (NT <= 8 && DP <= 128) ? 2 : (NT <= 4) ? 2 : 1;
+  return (NT <= 4 && DP <= BNPVI_FUSED_MINW3_DP) ? BNPVI_FUSED_MINW_SMALL : (NT <= 8 && DP <= 128) ? 2 : (NT <= 4) ? 2 : 1;
 }
 
 template <int DP, int NT, int PF, bool HARD, bool STATS>
