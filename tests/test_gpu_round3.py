@@ -460,7 +460,7 @@ def test_random_trajectories_against_oracle(seed):
 @pytest.mark.parametrize("seed", [5, 9])
 def test_random_trajectories_on_two_and_three_ranks(seed, tmp_path):
     """Two of the random trajectories of tests/traj_fuzz.py (seed 5 grows to K = 53, seed 9 to K = 328 through the
-    row-kernel regime) run by 2 and by 3 fresh processes over gloo (tests/dist_fuzz.py; 12 seeds swept in round 3):
+    row-kernel regime) run by 2 and by 3 fresh processes over gloo (tests/dist_fuzz.py; 33 seeds swept in round 3):
     after every call every rank holds the single-rank run's tree and parameters."""
     from tests import dist_fuzz
     want = dist_fuzz.run(1, seed, str(tmp_path / "w1"))[0]
