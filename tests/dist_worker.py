@@ -122,7 +122,14 @@ def main():
     torch.cuda.set_device(0)
     backend = os.environ.get("BNPVI_WORKER_BACKEND", "gloo")       # "nccl" (= RCCL): one rank per device only
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+            probe = torch.ones(4, dtype=torch.float64, device="cuda")
+            dist.all_reduce(probe)                                  # RCCL builds its communicator on first use
+            torch.cuda.synchronize()
+        except Exception as e:                                      # the machine's RCCL, not the code under test
+            print("nccl unavailable: %r" % (e,), flush=True)
+            os._exit(77)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     calls = {"all_reduce": 0, "all_gather": 0, "broadcast": 0}

@@ -291,6 +291,8 @@ def test_rccl_collectives_on_a_single_rank_group(tmp_path):
     env = dict(os.environ, BNPVI_WORKER_BACKEND="nccl", BNPVI_DIST_FORCE_COLLECTIVES="1")
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_worker.py"), "0", "1", str(_free_port()),
                         str(tmp_path), golden], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    if p.returncode == 77:
+        pytest.skip("RCCL could not set up a one-rank communicator on this machine: " + p.stdout[-300:])
     assert p.returncode == 0, p.stderr[-3000:]
     assert "collectives run: " in p.stdout and "backend nccl" in p.stdout, p.stdout[-2000:]
     counts = dict(kv.split("=") for kv in p.stdout.split("collectives run: ")[1].split()[:3])
