@@ -262,6 +262,39 @@ def test_streamed_general_epilogue_statistics_without_atomics(N, D, bf, levels):
     dev.close()
 
 
+@pytest.mark.parametrize("N,L_old,L_new", [
+    (1000, 64, 96),        # a 64-leaf tree after a split: 24 quads per row, ten rows per workgroup trip
+    (777, 100, 7),         # merge down to one padded block (8 quads)
+    (513, 1024, 900),      # 232 quads: one row per trip
+    (300, 900, 1100),      # more than 256 quads per row: the strided form
+    (129, 7776, 7700),     # config 4's tree
+    (1, 40, 33),
+])
+def test_remap_columns_against_numpy(N, L_old, L_new):
+    """bnpvi_remap_columns (phi re-laid out after split / merge; rewritten in round 3 to whole 16-byte quads per thread):
+    out[:, j] = scale[j] * in[:, src[j]] exactly, padding columns zero, for both forms of the kernel."""
+    import torch
+    from bnp_vae_amd import _lib
+    from bnp_vae_amd.engine import DeviceVI
+    rng = np.random.RandomState(L_old + L_new)
+    dev = DeviceVI(device=0)
+    Lp_old = _lib.padded_leaves(L_old)
+    phi = rng.random_sample((N, Lp_old)).astype(np.float32)
+    phi[:, L_old:] = 0
+    dev.N = N
+    dev.phi = torch.from_numpy(phi).to(dev.device)
+    src = rng.randint(0, L_old, size=L_new).astype(np.int32)
+    src[: min(L_new, L_old)] = np.sort(src[: min(L_new, L_old)])          # mostly ascending, as split / merge leave it
+    scale = rng.choice([1.0, 0.5, 0.25, 1.0 / 3.0], size=L_new).astype(np.float32)
+    dev.remap_phi(L_new, src, scale)
+    torch.cuda.synchronize()
+    got = dev.phi.cpu().numpy()
+    assert got.shape == (N, _lib.padded_leaves(L_new))
+    np.testing.assert_array_equal(got[:, :L_new], phi[:, src] * scale[None, :])
+    assert not got[:, L_new:].any()
+    dev.close()
+
+
 def _clustered_latents(N, D, ncomp, seed, ep, spread, noise):
     """Equal-mass tight clusters, fresh noise and a slow drift per epoch (legacy RandomState streams)."""
     rng = np.random.RandomState(seed)
